@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AD-Census (both views' [H,W,D] cost volumes + WTA) at 1920x1080, D=192.
+
+python bench.py --gpus N --steps K --warmup W
+One process per GPU (torch.distributed over RCCL when N > 1); pairs are independent, so
+each rank runs its own pairs with no data-path collective (weak scaling); one tiny
+all_gather of the last disparity map + a checksum all_reduce stand for config 5's gather.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (H, W, D, seed)
+    "adcensus_1080p_d192": (1080, 1920, 192, 3),   # BASELINE.json metric / configs[2] size
+    "adcensus_720p_d128": (720, 1280, 128, 2),     # configs[1]
+    "adcensus_kitti_d256": (375, 1242, 256, 1000), # configs[4] pair size
+}
+
+
+def cpu_baseline(H, W, D, seed, rows=64):
+    """Oracle (CPU 'port' of AD-Census.h:271-380), 1 thread, on a band of `rows` rows of the
+    SAME workload, both views + WTA.  Only this function touches oracle/."""
+    from oracle import oracle as orc
+    from stereo_match_traditional_amd import synth
+    L, R = synth.synth_pair(H, W, D, seed)
+    i0 = (H - rows) // 2
+    i1 = i0 + rows
+    t0 = time.perf_counter()
+    vl = orc.adcensus_view(L, R, D, 10.0, 30.0, 0, i0, i1)
+    vr = orc.adcensus_view(L, R, D, 10.0, 30.0, 1, i0, i1)
+    orc.wta(vl[i0:i1])
+    orc.wta(vr[i0:i1])
+    dt = time.perf_counter() - t0
+    hyp = rows * W * D
+    return {"value": round(hyp / dt / 1e6, 4), "unit": "Mdisp/s", "cores": 1, "kind": "port",
+            "sample": f"rows {i0}..{i1 - 1} of the {W}x{H} D={D} pair ({hyp / 1e6:.1f} M hypotheses, "
+                      f"both views + WTA, {dt:.1f} s, gcc -O2, 1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="adcensus_1080p_d192", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs-per-step", type=int, default=1)
+    ap.add_argument("--cpu-rows", type=int, default=64, help="rows in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import stereo_match_traditional_amd as smt
+    from stereo_match_traditional_amd import synth
+    from stereo_match_traditional_amd._lib import lib
+    lib()  # no fallback: fail here if the HIP library is missing
+
+    H, W, D, seed = WORKLOADS[args.workload]
+    P = args.pairs_per_step
+    Ls, Rs = zip(*[synth.synth_pair(H, W, D, seed + 7919 * rank + b) for b in range(P)])
+    Lb = torch.from_numpy(np.stack(Ls).astype(np.float32)).to(dev)
+    Rb = torch.from_numpy(np.stack(Rs).astype(np.float32)).to(dev)
+    dl = torch.empty((P, H, W), device=dev)
+    dr = torch.empty((P, H, W), device=dev)
+    adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, 10.0, 30.0)
+
+    def step():
+        adc.ComputeBatch(Lb, Rb, dl, dr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    adc.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        # config 5's only exchange: gather the disparity maps, all-reduce a checksum
+        gathered = [torch.empty_like(dl) for _ in range(world)]
+        dist.all_gather(gathered, dl)
+        chk = dl.sum(dtype=torch.float64)
+        dist.all_reduce(chk)
+    barrier()
+    dt = time.perf_counter() - t0
+    prep_ms, cost_ms = adc.kernel_times()
+    adc.timing(False)
+    adc.status()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        hyp_pair = H * W * D
+        total_pairs = world * P * args.steps
+        value = total_pairs * hyp_pair / dt / 1e6
+        # dominant kernel = k_cost: writes both views' float32 volumes, 8 B per hypothesis
+        alg_bytes = 8.0 * hyp_pair
+        k_ms = float(np.mean(cost_ms)) if cost_ms else float("nan")
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mdisparities/s (HxWxD/s) + ms/pair, AD-Census 1920x1080 D=192",
+            "value": round(value, 2),
+            "unit": "Mdisp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_pair": round(dt / (args.steps * P) * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"AD-Census 9x7 both views + WTA, {W}x{H} D={D} ({args.workload})",
+                       "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_cost (cost volume + fused WTA, both views)",
+                         "kernel_ms": round(k_ms, 4), "tables_ms": round(float(np.mean(prep_ms)), 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(H, W, D, seed, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,284 @@
+/*
+ * smt.h -- C ABI of the MI355X-native dense stereo cost-volume engine (libsmt_hip.so).
+ *
+ * This is the drop-in boundary for the per-pixel x per-disparity hot path of
+ * Asherchi/Stereo_Match_Traditional.  The reference has no FFI of its own: its
+ * boundary is the set of C++ entry points its five main()s call with raw buffers
+ * (SURVEY.md 8b).  Each entry point below names the reference function(s) it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the C++ shim a
+ * maintainer of the reference would add to route those calls here.
+ *
+ * Conventions
+ *   - plain C types only; every image / map / volume pointer is a DEVICE pointer (HIP
+ *     global memory) owned by the caller unless stated otherwise.  smt_malloc /
+ *     smt_memcpy_* are provided for hosts that have no allocator of their own.
+ *   - images  [H][W] row-major; volumes [H][W][D], d fastest, float32 -- the reference
+ *     layout (AD-CensusV1/AD-Census.h:87).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream unless documented as synchronising.
+ *   - every function returns SMT_OK (0) or a negative smt_status.  The reference
+ *     validates nothing (void functions, UB on bad sizes); this ABI rejects bad
+ *     arguments instead.
+ *   - handles are thread-compatible, not thread-safe (the reference objects hold
+ *     mutable state too, e.g. CrossArm.h:34 `_tao`).
+ *   - reference defects that change results are reproduced by default; see the
+ *     SMT_QUIRK_* flags.
+ */
+#ifndef SMT_H_
+#define SMT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMT_VERSION 100 /* 0.1.0 */
+
+typedef enum smt_status {
+    SMT_OK = 0,
+    SMT_ERR_ARG = -1,     /* null pointer / non-positive size / unsupported parameter */
+    SMT_ERR_HIP = -2,     /* a HIP runtime call failed (smt_last_hip_error has the code) */
+    SMT_ERR_ALLOC = -3,   /* device allocation failed */
+    SMT_ERR_DOMAIN = -4,  /* image values outside the integer 0..255 domain the path assumes */
+    SMT_ERR_REF_UB = -5,  /* inputs for which the reference's behaviour is undefined */
+    SMT_ERR_STATE = -6    /* call order violated (e.g. aggregate before arms) */
+} smt_status;
+
+/* Reference-defect switches.  Default (0) = reference-faithful. */
+#define SMT_QUIRK_FIX_RIGHT_ARM_STRIDE 0x1u /* undo `col = _row` in ComputeRightArmLength (CrossArm.cpp:265) */
+
+/* views bit mask */
+#define SMT_VIEW_LEFT 1
+#define SMT_VIEW_RIGHT 2
+#define SMT_VIEW_BOTH 3
+
+const char *smt_strerror(int status);
+int smt_version(void);
+int smt_last_hip_error(void);
+int smt_device_count(int *count);
+int smt_set_device(int device);
+
+/* ---- device memory helpers (plumbing; not part of the reference's surface) ---------- */
+int smt_malloc(void **dptr, size_t bytes);
+int smt_free(void *dptr);
+int smt_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int smt_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int smt_memset(void *dst_dev, int byte, size_t bytes, void *stream);
+int smt_stream_create(void **stream);
+int smt_stream_destroy(void *stream);
+int smt_stream_sync(void *stream); /* synchronising */
+
+/* ---- kernel timing (bench.py roofline leg) ----------------------------------------------
+ * When enabled, every pair processed on the handle records three HIP events on the
+ * handle's stream (before the table kernels, between tables and cost kernel, after the
+ * cost kernel) into a ring of `SMT_TIMING_SLOTS` slots; nothing synchronises until
+ * smt_adcensus_kernel_times, which waits for the last event and returns the per-pair
+ * durations in milliseconds, oldest first. */
+#define SMT_TIMING_SLOTS 1024
+typedef struct smt_adcensus smt_adcensus;
+int smt_adcensus_timing(smt_adcensus *h, int enable); /* also clears the ring */
+int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *cost_ms, int capacity,
+                              int *count);
+
+/* =====================================================================================
+ * AD-Census cost volume + WTA        replaces class AD_Census, AD-CensusV1/AD-Census.h
+ * ===================================================================================== */
+
+/* AD_Census::Initialize (AD-Census.h:322-344): fixes H, W, D, sigmaC (AD, `_sigmaC`) and
+ * sigmaS (census, `_sigmaS`); allocates the left and right cost volumes (costVolume,
+ * costVolumeRight) plus census tables.  The reference's separate AD / census volumes
+ * (ADcostVolum, CensusVolum, ...) are never materialised. */
+int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out);
+int smt_adcensus_destroy(smt_adcensus *h);
+int smt_adcensus_set_stream(smt_adcensus *h, void *stream);
+
+/* ComputeADcensus (AD-Census.h:271-294) for SMT_VIEW_LEFT, ComputeADcensusRight
+ * (:296-318) for SMT_VIEW_RIGHT, followed -- when dispL / dispR are non-NULL -- by
+ * AD_Census::WTA (:346-380) fused into the same kernel.
+ *   L, R        float32 [H][W], integer-valued 0..255 (main.cpp:46-55 builds them from
+ *               uchar gray images); anything else raises SMT_ERR_DOMAIN at the next
+ *               smt_adcensus_status.
+ *   dispL/R     float32 [H][W] out, integer-valued, may be NULL. */
+int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R, int views,
+                         float *dispL, float *dispR);
+
+/* Same, for a batch of `pairs` image pairs laid out [pairs][H][W]; the volumes are
+ * reused per pair (only the last pair's stay readable), the disparity maps are
+ * [pairs][H][W].  This is the sharding unit of the multi-GPU configuration. */
+int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
+                               int views, float *dispL, float *dispR);
+
+/* GetPtrLeft / GetPtrRight (AD-Census.h:50-72): borrowed device pointer, valid until
+ * destroy. view = SMT_VIEW_LEFT or SMT_VIEW_RIGHT. */
+int smt_adcensus_volume(smt_adcensus *h, int view, float **vol);
+
+/* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen so far was not an
+ * integer in 0..255 (then the volumes are unspecified), else SMT_OK. */
+int smt_adcensus_status(smt_adcensus *h);
+
+/* First-strict-minimum argmin over d of one volume.  Replaces
+ * CrossArmAggregation::WTA (CrossArm.cpp:33-57), ScanlineOptimizer::WTA
+ * (ScanlineOptimizer.h:40-64), ComputeDispOringin (CBLSM/CBLSM.h:383-407) and, applied
+ * twice, AD_Census::WTA. */
+int smt_wta(const float *vol, int H, int W, int D, float *disp, void *stream);
+
+/* =====================================================================================
+ * Cross-arm rectangle aggregation     replaces class CrossArmAggregation
+ *                                     (AD-CensusV1/CrossArm.{h,cpp}) and the active
+ *                                     CBLSM.h functions ArmLength{L,R,Up,Down},
+ *                                     costAggregationV5
+ * ===================================================================================== */
+typedef struct smt_crossarm smt_crossarm;
+
+typedef struct smt_crossarm_params {
+    int tau;          /* initial threshold: 30 (main.cpp:27) / 25 (CBLSM.cpp:30) */
+    int tau_low;      /* 6  (CrossArm.cpp:225, CBLSM.h:719) */
+    int sec_length;   /* 17 (CrossArm.cpp:223) / secLength (CBLSM.cpp:32) */
+    int max_length;   /* 34 (CrossArm.cpp:226) / maxLength (CBLSM.cpp:31) */
+    int chain_tau;    /* 1: `_tao` is a member, sticky across the four direction calls
+                            (CrossArm.h:34); 0: by-value per call (CBLSM.h:643) */
+    unsigned quirks;  /* SMT_QUIRK_*; 0 = faithful.  CBLSM-style arms have no stride bug:
+                            pass SMT_QUIRK_FIX_RIGHT_ARM_STRIDE for them. */
+} smt_crossarm_params;
+
+void smt_crossarm_default_params(smt_crossarm_params *p); /* AD-CensusV1 main.cpp values */
+void smt_crossarm_cblsm_params(smt_crossarm_params *p);   /* CBLSM.cpp values */
+
+/* CrossArmAggregation::Initialize (CrossArm.cpp:6-18): allocates the four arm maps and
+ * resets the sticky threshold. */
+int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out);
+int smt_crossarm_destroy(smt_crossarm *h);
+int smt_crossarm_set_stream(smt_crossarm *h, void *stream);
+
+/* ComputeLeftArmLength, ComputeRightArmLength, ComputeTopArmLength,
+ * ComputeButtonArmLength (CrossArm.cpp:147-598) in that order with the threshold state
+ * chained as the reference's member does.  Resets the threshold first, i.e. it is
+ * Initialize + the four calls of main.cpp:68-72.
+ *   img        uint8 [H][W][channels], channels 1 (gray branch) or 3 (Vec3b branch). */
+int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels);
+
+/* Borrowed pointers to the int32 [H][W] arm maps (leftLength, rightLength, topLength,
+ * buttonLenght; CrossArm.h:30-33). */
+int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, int **bottom);
+
+/* order 0: AggregationVertical (CrossArm.cpp:60-102), columns outer / rows inner;
+ * order 1: costAggregationV5 (CBLSM.h:1179-1224), rows outer / columns inner.
+ * Sequential float adds in exactly that order, divided by the tap count.
+ * If disp != NULL the WTA of the aggregated volume is fused (CrossArm.cpp:33-57).
+ * Returns SMT_ERR_REF_UB from smt_crossarm_status when a rectangle leaves the plane
+ * (possible with the right-arm stride bug on small / non-landscape images). */
+int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out, int order,
+                           float *disp);
+int smt_crossarm_status(smt_crossarm *h); /* synchronising */
+
+/* CBLSM.h:327-381 ComputeAD / ComputeADRight on uchar images -> float volume. */
+int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int view, float *vol,
+                 void *stream);
+
+/* =====================================================================================
+ * Scanline optimiser                  replaces class ScanlineOptimizer
+ *                                     (AD-CensusV1/ScanlineOptimizer.h)
+ * ===================================================================================== */
+typedef struct smt_scanline smt_scanline;
+
+/* ScanlineOptimizer::Initialize (:66-79).  The reference allocates five volumes; this
+ * engine keeps one scratch volume. */
+int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanline **out);
+int smt_scanline_destroy(smt_scanline *h);
+int smt_scanline_set_stream(smt_scanline *h, void *stream);
+
+/* ScanlineOptimizer::ScanLine (:104-128): the four passes and ((left+right)+up)+down,
+ * written to vol_out (`_ProcessedVolume`).  gray: float32 [H][W] guidance image
+ * (`leftptr`, main.cpp:88).  If disp != NULL, ScanlineOptimizer::WTA (:40-64) is fused.
+ * vol_out must not alias vol_in. */
+int smt_scanline_run(smt_scanline *h, const float *vol_in, const float *gray, float *vol_out,
+                     float *disp);
+
+/* One path volume only (leftVolume/rightVolume/upVolume/downVolume), for tests.
+ * pass: 0 left->right (isLeft=true), 1 right->left, 2 top->bottom (isUp=true), 3 bottom->top. */
+int smt_scanline_pass(smt_scanline *h, const float *vol_in, const float *gray, int pass,
+                      float *vol_out);
+
+/* =====================================================================================
+ * Left-right consistency              replaces LeftRightConsistency
+ *                                     (AD-CensusV1/PostProcessing.h:72-135)
+ * ===================================================================================== */
+/* In place on dispL (invalid -> +inf).  cls: uint8 [H][W], 0 kept / 1 occlusion /
+ * 2 mismatch; the reference's two vectors are these classes in row-major order
+ * (smt_lrcheck_lists rebuilds them on the host).  counts: device int32[2] = {occlusions,
+ * mismatches}, may be NULL. */
+int smt_lrcheck(float *dispL, const float *dispR, int H, int W, int gate, uint8_t *cls,
+                int *counts, void *stream);
+
+/* Host helper: expand a HOST copy of cls into the reference's (row, col) pair lists.
+ * Each list must have room for H*W pairs (2 ints per pair); returns counts. */
+int smt_lrcheck_lists(const uint8_t *cls_host, int H, int W, int *occlusion_pairs, int *n_occ,
+                      int *mismatch_pairs, int *n_mis);
+
+/* =====================================================================================
+ * CrossAggregator (vendored ethan-li AD-Census)   replaces class CrossAggregator
+ *                                     (CBLSM/cross_aggregator.{h,cpp})
+ * ===================================================================================== */
+typedef struct smt_crossagg smt_crossagg;
+
+/* Initialize(width,height,min_disparity,max_disparity) (:19-58). D = max-min.
+ * Returns SMT_ERR_ARG where the reference returns false. */
+int smt_crossagg_create(int W, int H, int D, smt_crossagg **out);
+int smt_crossagg_destroy(smt_crossagg *h);
+int smt_crossagg_set_stream(smt_crossagg *h, void *stream);
+/* SetParams (:67-74); defaults L1=34 L2=17 t1=20 t2=6 (adcensus_types.h:69-70). */
+int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int t2);
+/* SetData + Aggregate(num_iters) (:60-65, :89-118).  img_left: uint8 [H][W][3];
+ * cost_init: float32 [H][W][D].  The result stays in the handle (get_cost_ptr). */
+int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img_left, const float *cost_init,
+                           int num_iters);
+/* get_cost_ptr (:125-133) / get_arms_ptr (:120-123): borrowed. arms: uint8 [H][W][4] =
+ * left,right,top,bottom (struct CrossArm, cross_aggregator.h:17-20). */
+int smt_crossagg_cost(smt_crossagg *h, float **cost);
+int smt_crossagg_arms(smt_crossagg *h, uint8_t **arms);
+
+/* =====================================================================================
+ * Window matchers                     replace SAD/Sad.h, NCC/NCC.h, ASW/ASW.h
+ * ===================================================================================== */
+/* GetPointDepthLeft (Sad.h:96-139, view SMT_VIEW_LEFT, WTA = OptimalDisparity :40-85) /
+ * GetPointDepthRight (:141-182, view SMT_VIEW_RIGHT, WTA = GetMinSadIndex :22-38).
+ * Lp, Rp: uint8 [H+2w][W+2w] replicate-padded by w = winsize+1 (SADmain.cpp:47-48);
+ * window side 2w+1.  disp: int32 [H][W] (right view leaves the last row/column 0). */
+int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winsize, int view,
+            int32_t *disp, void *stream);
+/* CrossCheckDiaparity (Sad.h:184-222).  out int32 [H][W] (invalid = INT32_MIN, the x86
+ * value of the reference's int(inf)); cls as smt_lrcheck. */
+int smt_sad_crosscheck(const int32_t *dispL, const int32_t *dispR, int H, int W, int32_t *out,
+                       uint8_t *cls, void *stream);
+
+/* NCC_algorithem (NCC.h:69-95) = ComputeCost (:15-49, float64) + WinTakeAll (:53-67,
+ * argMAX with a float32-narrowed running maximum).  L, R uint8 [H][W] unpadded; only the
+ * interior winSize <= i < H-winSize, winSize <= j < W-winSize is written, the rest of
+ * disp is set to 0.  cost (optional, may be NULL): float64 [H][W][D] per-hypothesis
+ * costs for tolerance checks. */
+int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int winSize, int32_t *disp,
+            double *cost, void *stream);
+
+/* getGausssianMask (ASW.h:16-35) and getColorMask (:41-47), computed on the HOST in
+ * float64 exactly as the reference does.  space: (2*winSize+3)^2 doubles, color: 256. */
+int smt_asw_masks(int winSize, double sigma_space, double sigma_color, double *space_host,
+                  double *color_host);
+
+/* AdaptiveSupportWeight (ASW.h:329-378, SMT_VIEW_LEFT) / AdaptiveSupportWeightRight
+ * (:382-431, SMT_VIEW_RIGHT): bilateralfiterWight (:210-257) per hypothesis + WinTakeAll
+ * (:193-208).  Lp, Rp: uint8 [H+2w][W+2w] replicate-padded by w = winSize+1
+ * (ASWeight.cpp:54-57); space/color: DEVICE float64 tables from smt_asw_masks; T: error
+ * truncation.  disp float32 [H][W]; cost (optional) float32 [H][W][D]. */
+int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSize,
+            const double *space, const double *color, int T, int view, float *disp, float *cost,
+            void *stream);
+/* CrossCheckDiaparity (ASW.h:108-145): float maps -> uint8 map, 0 = rejected. */
+int smt_asw_crosscheck(const float *dispL, const float *dispR, int H, int W, uint8_t *out,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMT_H_ */

@@ -1,0 +1,536 @@
+// AD + 9x7 census cost volume with fused WTA -- replaces class AD_Census
+// (AD-CensusV1/AD-Census.h) for both views.
+//
+// Formulation (different from the reference's per-(i,j,d) census rebuild, AD-Census.h:142-269,
+// same results):
+//   left  view: census(i,j,d) = popcount((cenA_L[i][j] ^ cenX_R[i][max(j-d,-3)]) & M[i][j])
+//               AD(i,j,d)     = |L[i][j] - R[i][max(j-d,0)]|
+//   right view: census(i,j,d) = popcount((cenA_R[i][j] ^ cenX_L[i][min(j+d,W+3)]) & M[i][j])
+//               AD(i,j,d)     = |L[i][min(j+d,W-1)] - R[i][j]|
+// with cenA_* the ordinary 63-bit census of the anchor image (invalid taps = 0), M the
+// in-image tap mask of the anchor pixel (validity is tested on anchor coordinates,
+// AD-Census.h:173 / :238), cenX_R the right image's census on a left-replicate-extended
+// row (:159-160, :177-178) and cenX_L the left image's census with the reference's
+// "column 0 past the right edge" rule for neighbours and "column W-1" rule for the
+// centre (:224-225, :242-243).  The "copy d-1" branches of ComputeAD (:88-92, :116-120)
+// are exactly the clamps above.
+//   cost = lutA[AD] + lutC[census], lutA[k] = 1-expf(-(k/sigmaC)), lutC[k] = 1-expf(-(k/sigmaS))
+// built on the HOST with the reference's own float expression (:287-289), so the device
+// never evaluates exp.  AD in 0..255 and census in 0..63 because images are integer-valued.
+//
+// Main kernel: one wavefront spans the disparity axis of one pixel; lane l owns the C =
+// D/64 consecutive hypotheses d = l*C .. l*C+C-1 and stores them with one
+// dword/x2/x3/x4 store (64*C*4 contiguous bytes per wave).  Row operands are staged in
+// LDS once per workgroup; WTA is a wave min + ballot (first strict minimum, :355-373).
+#include "smt_common.h"
+#include <math.h>
+#include <new>
+
+namespace {
+
+constexpr int TJ = 64;        // pixels per workgroup
+constexpr int NT = 256;       // threads per workgroup (4 waves)
+
+struct Tables {
+    // per view v (0 = left anchor, 1 = right anchor)
+    uint64_t *cenA[2];   // [H][W]
+    uint64_t *cenX[2];   // [H][WX]   view0: index x+3, x in [-3,W-1]; view1: index x, x in [0,W+3]
+    uint64_t *mask;      // [H][W]
+    uint8_t *u8[2];      // [H][W] left, right as bytes
+    float *lut;          // 256 + 64 floats
+    int *flag;           // domain flag
+    int WX;
+};
+
+// ---- tap validity mask + the four census tables --------------------------------------
+// bit layout: tap t = (r+4)*7 + (c+3), r in [-4,4] outer, c in [-3,3] inner, MSB first:
+// bit (62 - t)  (63 left shifts of a 64-bit word, AD-Census.h:171-172).
+__global__ void __launch_bounds__(256) k_prep(const float *__restrict__ Lf,
+                                              const float *__restrict__ Rf, int H, int W, Tables T)
+{
+    const int i = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. WX-1
+    const int WX = T.WX;
+    if (x >= WX) return;
+    const uint8_t *Lb = T.u8[0], *Rb = T.u8[1];
+
+    if (x < W) {
+        // anchor censuses + mask at pixel (i, x)
+        const int lc = Lb[i * W + x], rc = Rb[i * W + x];
+        uint64_t cl = 0, cr = 0, m = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                cl <<= 1; cr <<= 1; m <<= 1;
+                const int jj = x + c;
+                if (rv && jj >= 0 && jj < W) {
+                    m |= 1;
+                    cl |= (uint64_t)(lc > (int)Lb[ii * W + jj]);
+                    cr |= (uint64_t)(rc > (int)Rb[ii * W + jj]);
+                }
+            }
+        }
+        T.cenA[0][(size_t)i * W + x] = cl;
+        T.cenA[1][(size_t)i * W + x] = cr;
+        T.mask[(size_t)i * W + x] = m;
+    }
+    // cenX_R at xr = x-3 in [-3, W-1] (table index x in [0, W+2])
+    if (x <= W + 2) {
+        const int xr = x - 3;
+        const int cc = xr < 0 ? 0 : xr;
+        const int rc = Rb[i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                w <<= 1;
+                int jj = xr + c;
+                if (jj < 0) jj = 0;                      // left replicate (:177-178)
+                if (rv && jj < W) w |= (uint64_t)(rc > (int)Rb[ii * W + jj]);
+            }
+        }
+        T.cenX[0][(size_t)i * WX + x] = w;
+    }
+    // cenX_L at xl = x in [0, W+3]
+    if (x <= W + 3) {
+        const int cc = x > W - 1 ? W - 1 : x;            // centre clamps to W-1 (:224-225)
+        const int lc = Lb[i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                w <<= 1;
+                int jj = x + c;
+                if (jj >= W) jj = 0;                     // neighbour wraps to column 0 (:242-243)
+                if (rv && jj >= 0) w |= (uint64_t)(lc > (int)Lb[ii * W + jj]);
+            }
+        }
+        T.cenX[1][(size_t)i * WX + x] = w;
+    }
+}
+
+// float image -> u8 image + domain check
+__global__ void __launch_bounds__(256) k_to_u8(const float *__restrict__ Lf,
+                                               const float *__restrict__ Rf, int n, uint8_t *Lb,
+                                               uint8_t *Rb, int *flag)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float a = Lf[k], b = Rf[k];
+    const int ia = (int)a, ib = (int)b;
+    const bool bad = !(a >= 0.0f && a <= 255.0f && (float)ia == a) ||
+                     !(b >= 0.0f && b <= 255.0f && (float)ib == b);
+    Lb[k] = (uint8_t)ia;
+    Rb[k] = (uint8_t)ib;
+    if (bad) atomicOr(flag, 1);
+}
+
+template <int C> struct vecf;
+template <> struct vecf<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
+template <> struct vecf<3> { float v[3]; };
+template <> struct __attribute__((aligned(16))) vecf<4> { float v[4]; };
+
+// ---- cost volume + WTA ---------------------------------------------------------------
+// grid: (ceil(W/TJ), H, nviews)   block: 256
+// FULL: D == 64*C (every lane active, vector store); otherwise C = ceil(D/64) with tail
+// lanes masked and scalar stores.
+template <int C, bool FULL>
+__global__ void __launch_bounds__(NT) k_cost(int H, int W, int D, Tables T, int view0,
+                                             float *__restrict__ vol0, float *__restrict__ vol1,
+                                             float *__restrict__ disp0, float *__restrict__ disp1)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int view = view0 + blockIdx.z;
+    const int i = blockIdx.y;
+    const int j0 = blockIdx.x * TJ;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int NX = TJ + D;                                  // staged ext entries (>= TJ + D - 1)
+
+    uint64_t *s_cenx = (uint64_t *)smem;                    // NX
+    uint64_t *s_cena = s_cenx + NX;                         // TJ
+    uint64_t *s_mask = s_cena + TJ;                         // TJ
+    float *s_lutA = (float *)(s_mask + TJ);                 // 256
+    float *s_lutC = s_lutA + 256;                           // 64
+    uint8_t *s_valx = (uint8_t *)(s_lutC + 64);             // NX
+    uint8_t *s_vala = s_valx + NX;                          // TJ
+
+    const int WX = T.WX;
+    const uint64_t *cenX = T.cenX[view] + (size_t)i * WX;
+    const uint8_t *extv = T.u8[view ^ 1] + (size_t)i * W;   // left view reads R, right view reads L
+    const uint8_t *ancv = T.u8[view] + (size_t)i * W;
+    // staged entry e <-> ext coordinate x:  view 0: x = j0 - (D-1) + e ; view 1: x = j0 + e
+    const int xbase = (view == 0) ? (j0 - (D - 1)) : j0;
+    for (int e = tid; e < NX; e += NT) {
+        int x = xbase + e;
+        int xc, xv;
+        if (view == 0) {
+            xc = x < -3 ? -3 : (x > W - 1 ? W - 1 : x);
+            xv = xc < 0 ? 0 : xc;
+            xc += 3;
+        } else {
+            xc = x > W + 3 ? W + 3 : x;
+            xv = x > W - 1 ? W - 1 : x;
+        }
+        s_cenx[e] = cenX[xc];
+        s_valx[e] = extv[xv];
+    }
+    for (int e = tid; e < TJ; e += NT) {
+        int j = j0 + e;
+        if (j > W - 1) j = W - 1;
+        s_cena[e] = T.cenA[view][(size_t)i * W + j];
+        s_mask[e] = T.mask[(size_t)i * W + j];
+        s_vala[e] = ancv[j];
+    }
+    for (int e = tid; e < 320; e += NT) s_lutA[e] = T.lut[e];
+    __syncthreads();
+
+    float *vol = view == 0 ? vol0 : vol1;
+    float *disp = view == 0 ? disp0 : disp1;
+    const int dl = lane * C;                                // first hypothesis of this lane
+
+    for (int p = wid; p < TJ; p += NT / 64) {
+        const int j = j0 + p;
+        if (j >= W) break;
+        const uint64_t ca = s_cena[p], mk = s_mask[p];
+        const int va = s_vala[p];
+        // ext entry of hypothesis d: view 0: e = p + (D-1) - d ; view 1: e = p + d
+        float c[C];
+        float best = 0.0f; int bestk = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const int d = dl + k;
+            int e = (view == 0) ? (p + (D - 1) - d) : (p + d);
+            if (!FULL) e = (d < D) ? e : 0;
+            const uint64_t x = (ca ^ s_cenx[e]) & mk;
+            const int hd = __popcll(x);
+            int ad = va - (int)s_valx[e];
+            ad = ad < 0 ? -ad : ad;
+            const float cost = s_lutA[ad] + s_lutC[hd];
+            c[k] = cost;
+            if (k == 0) { best = cost; bestk = 0; }
+            else if (best > cost) { best = cost; bestk = k; }
+        }
+        float *out = vol + ((size_t)i * W + j) * D + dl;
+        if (FULL) {
+            vecf<C> pk;
+#pragma unroll
+            for (int k = 0; k < C; k++) pk.v[k] = c[k];
+            *reinterpret_cast<vecf<C> *>(out) = pk;
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+                if (dl + k < D) out[k] = c[k];
+        }
+        if (disp) {
+            float bv = best;
+            if (!FULL) {
+                // lanes past D must never win; lanes straddling D keep only their valid prefix
+                if (dl >= D) bv = INFINITY;
+                else if (dl + C > D) {
+                    bv = c[0]; bestk = 0;
+#pragma unroll
+                    for (int k = 1; k < C; k++)
+                        if (dl + k < D && bv > c[k]) { bv = c[k]; bestk = k; }
+                }
+            }
+            const int wd = wave_argmin_first(bv, dl + bestk);
+            if (lane == 0) disp[(size_t)i * W + j] = (float)wd;
+        }
+    }
+}
+
+// generic WTA over an existing volume: one wave per pixel.
+template <int C>
+__global__ void __launch_bounds__(NT) k_wta(const float *__restrict__ vol, int N, int D,
+                                            float *__restrict__ disp)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (p >= N) return;
+    const float *c = vol + (size_t)p * D;
+    float best = INFINITY; int bd = 0;
+    const int dl = lane * C;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const int d = dl + k;
+        if (d < D) {
+            const float v = c[d];
+            if (k == 0 || best > v) { best = v; bd = d; }
+        }
+    }
+    if (dl >= D) best = INFINITY;
+    const int wd = wave_argmin_first(best, bd);
+    if (lane == 0) disp[p] = (float)wd;
+}
+
+}  // namespace
+
+thread_local int g_smt_last_hip = 0;
+
+struct smt_adcensus {
+    int H, W, D;
+    float sigmaC, sigmaS;
+    hipStream_t stream;
+    float *vol[2];
+    Tables T;
+    hipEvent_t *ev;      // SMT_TIMING_SLOTS * 3, lazily created
+    bool timing;
+    long n_timed;        // pairs recorded since timing was (re-)enabled
+};
+
+SMT_API const char *smt_strerror(int s)
+{
+    switch (s) {
+    case SMT_OK: return "ok";
+    case SMT_ERR_ARG: return "invalid argument";
+    case SMT_ERR_HIP: return "HIP runtime error";
+    case SMT_ERR_ALLOC: return "device allocation failed";
+    case SMT_ERR_DOMAIN: return "image values outside the integer 0..255 domain";
+    case SMT_ERR_REF_UB: return "reference behaviour undefined for these inputs";
+    case SMT_ERR_STATE: return "call order violated";
+    default: return "unknown status";
+    }
+}
+SMT_API int smt_version(void) { return SMT_VERSION; }
+SMT_API int smt_last_hip_error(void) { return g_smt_last_hip; }
+SMT_API int smt_device_count(int *n)
+{
+    if (!n) return SMT_ERR_ARG;
+    SMT_HIP(hipGetDeviceCount(n));
+    return SMT_OK;
+}
+SMT_API int smt_set_device(int d) { SMT_HIP(hipSetDevice(d)); return SMT_OK; }
+SMT_API int smt_malloc(void **p, size_t n)
+{
+    if (!p) return SMT_ERR_ARG;
+    hipError_t e = hipMalloc(p, n ? n : 1);
+    if (e != hipSuccess) { g_smt_last_hip = (int)e; return SMT_ERR_ALLOC; }
+    return SMT_OK;
+}
+SMT_API int smt_free(void *p) { SMT_HIP(hipFree(p)); return SMT_OK; }
+SMT_API int smt_memcpy_h2d(void *d, const void *s, size_t n, void *st)
+{
+    SMT_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, smt_stream(st)));
+    return SMT_OK;
+}
+SMT_API int smt_memcpy_d2h(void *d, const void *s, size_t n, void *st)
+{
+    SMT_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, smt_stream(st)));
+    return SMT_OK;
+}
+SMT_API int smt_memset(void *d, int b, size_t n, void *st)
+{
+    SMT_HIP(hipMemsetAsync(d, b, n, smt_stream(st)));
+    return SMT_OK;
+}
+SMT_API int smt_stream_create(void **s)
+{
+    if (!s) return SMT_ERR_ARG;
+    hipStream_t st;
+    SMT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *s = (void *)st;
+    return SMT_OK;
+}
+SMT_API int smt_stream_destroy(void *s) { SMT_HIP(hipStreamDestroy(smt_stream(s))); return SMT_OK; }
+SMT_API int smt_stream_sync(void *s) { SMT_HIP(hipStreamSynchronize(smt_stream(s))); return SMT_OK; }
+
+SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
+{
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256 || !(sigmaC > 0.0f) || !(sigmaS > 0.0f))
+        return SMT_ERR_ARG;
+    smt_adcensus *h = new (std::nothrow) smt_adcensus();
+    if (!h) return SMT_ERR_ALLOC;
+    h->H = H; h->W = W; h->D = D; h->sigmaC = sigmaC; h->sigmaS = sigmaS;
+    h->stream = nullptr; h->timing = false; h->ev = nullptr; h->n_timed = 0;
+    const size_t N = (size_t)H * W, V = N * D;
+    const int WX = W + 4;
+    h->T.WX = WX;
+    int rc = SMT_OK;
+    auto alloc = [&](void **p, size_t bytes) { if (rc == SMT_OK) rc = smt_malloc(p, bytes); };
+    alloc((void **)&h->vol[0], V * 4); alloc((void **)&h->vol[1], V * 4);
+    for (int v = 0; v < 2; v++) {
+        alloc((void **)&h->T.cenA[v], N * 8);
+        alloc((void **)&h->T.cenX[v], (size_t)H * WX * 8);
+        alloc((void **)&h->T.u8[v], N);
+    }
+    alloc((void **)&h->T.mask, N * 8);
+    alloc((void **)&h->T.lut, 320 * 4);
+    alloc((void **)&h->T.flag, 4);
+    if (rc != SMT_OK) { smt_adcensus_destroy(h); return rc; }
+    // fusion tables, the reference's own float expression (AD-Census.h:287-288)
+    float lut[320];
+    for (int k = 0; k < 256; k++) lut[k] = 1.0f - expf(-((float)k / sigmaC));
+    for (int k = 0; k < 64; k++) lut[256 + k] = 1.0f - expf(-((float)k / sigmaS));
+    if (hipMemcpy(h->T.lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->T.flag, 0, 4) != hipSuccess) {
+        smt_adcensus_destroy(h);
+        return SMT_ERR_HIP;
+    }
+    *out = h;
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_destroy(smt_adcensus *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    (void)hipFree(h->vol[0]); (void)hipFree(h->vol[1]);
+    for (int v = 0; v < 2; v++) {
+        (void)hipFree(h->T.cenA[v]); (void)hipFree(h->T.cenX[v]); (void)hipFree(h->T.u8[v]);
+    }
+    (void)hipFree(h->T.mask); (void)hipFree(h->T.lut); (void)hipFree(h->T.flag);
+    if (h->ev) {
+        for (int k = 0; k < SMT_TIMING_SLOTS * 3; k++) (void)hipEventDestroy(h->ev[k]);
+        delete[] h->ev;
+    }
+    delete h;
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_set_stream(smt_adcensus *h, void *s)
+{
+    if (!h) return SMT_ERR_ARG;
+    h->stream = smt_stream(s);
+    return SMT_OK;
+}
+
+template <int C, bool FULL>
+static void launch_cost(smt_adcensus *h, int view0, int nviews, float *d0, float *d1)
+{
+    const int D = h->D;
+    dim3 grid((h->W + TJ - 1) / TJ, h->H, nviews);
+    const int NX = TJ + D;
+    size_t shm = (size_t)NX * 8 + TJ * 16 + 320 * 4 + NX + TJ;
+    shm = (shm + 15) & ~(size_t)15;
+    hipLaunchKernelGGL((k_cost<C, FULL>), grid, dim3(NT), shm, h->stream, h->H, h->W, D, h->T,
+                       view0, h->vol[0], h->vol[1], d0, d1);
+}
+
+static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int views, float *dL,
+                         float *dR)
+{
+    const int H = h->H, W = h->W, D = h->D, N = H * W;
+    const bool timed = h->timing;
+    hipEvent_t *ev = timed ? h->ev + 3 * (h->n_timed % SMT_TIMING_SLOTS) : nullptr;
+    if (timed) (void)hipEventRecord(ev[0], h->stream);
+    hipLaunchKernelGGL(k_to_u8, dim3((N + 255) / 256), dim3(256), 0, h->stream, L, R, N,
+                       h->T.u8[0], h->T.u8[1], h->T.flag);
+    hipLaunchKernelGGL(k_prep, dim3((h->T.WX + 255) / 256, H), dim3(256), 0, h->stream, L, R, H, W,
+                       h->T);
+    if (timed) (void)hipEventRecord(ev[1], h->stream);
+    const int view0 = (views & SMT_VIEW_LEFT) ? 0 : 1;
+    const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
+    const int C = (D + 63) / 64;
+    const bool full = (D % 64) == 0;
+    switch (C * 2 + (full ? 1 : 0)) {
+    case 3: launch_cost<1, true>(h, view0, nviews, dL, dR); break;
+    case 5: launch_cost<2, true>(h, view0, nviews, dL, dR); break;
+    case 7: launch_cost<3, true>(h, view0, nviews, dL, dR); break;
+    case 9: launch_cost<4, true>(h, view0, nviews, dL, dR); break;
+    case 2: launch_cost<1, false>(h, view0, nviews, dL, dR); break;
+    case 4: launch_cost<2, false>(h, view0, nviews, dL, dR); break;
+    case 6: launch_cost<3, false>(h, view0, nviews, dL, dR); break;
+    case 8: launch_cost<4, false>(h, view0, nviews, dL, dR); break;
+    default: return SMT_ERR_ARG;
+    }
+    if (timed) { (void)hipEventRecord(ev[2], h->stream); h->n_timed++; }
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R, int views,
+                                 float *dispL, float *dispR)
+{
+    if (!h || !L || !R || views < 1 || views > 3) return SMT_ERR_ARG;
+    return adcensus_pair(h, L, R, views, dispL, dispR);
+}
+
+SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
+                                       int views, float *dispL, float *dispR)
+{
+    if (!h || !L || !R || pairs <= 0 || views < 1 || views > 3) return SMT_ERR_ARG;
+    const size_t N = (size_t)h->H * h->W;
+    for (int b = 0; b < pairs; b++) {
+        int rc = adcensus_pair(h, L + b * N, R + b * N, views, dispL ? dispL + b * N : nullptr,
+                               dispR ? dispR + b * N : nullptr);
+        if (rc != SMT_OK) return rc;
+    }
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_volume(smt_adcensus *h, int view, float **vol)
+{
+    if (!h || !vol || (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT)) return SMT_ERR_ARG;
+    *vol = h->vol[view == SMT_VIEW_LEFT ? 0 : 1];
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_status(smt_adcensus *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    int f = 0;
+    SMT_HIP(hipMemcpyAsync(&f, h->T.flag, 4, hipMemcpyDeviceToHost, h->stream));
+    SMT_HIP(hipStreamSynchronize(h->stream));
+    return f ? SMT_ERR_DOMAIN : SMT_OK;
+}
+
+SMT_API int smt_adcensus_timing(smt_adcensus *h, int enable)
+{
+    if (!h) return SMT_ERR_ARG;
+    if (enable && !h->ev) {
+        h->ev = new (std::nothrow) hipEvent_t[SMT_TIMING_SLOTS * 3];
+        if (!h->ev) return SMT_ERR_ALLOC;
+        for (int k = 0; k < SMT_TIMING_SLOTS * 3; k++) SMT_HIP(hipEventCreate(&h->ev[k]));
+    }
+    h->timing = enable != 0;
+    h->n_timed = 0;
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *cost_ms, int capacity,
+                                      int *count)
+{
+    if (!h || !count || capacity < 0) return SMT_ERR_ARG;
+    if (!h->ev) return SMT_ERR_STATE;
+    long n = h->n_timed < SMT_TIMING_SLOTS ? h->n_timed : SMT_TIMING_SLOTS;
+    if (n > capacity) n = capacity;
+    const long first = h->n_timed - n;
+    for (long k = 0; k < n; k++) {
+        hipEvent_t *ev = h->ev + 3 * ((first + k) % SMT_TIMING_SLOTS);
+        SMT_HIP(hipEventSynchronize(ev[2]));
+        float a = 0, b = 0;
+        SMT_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+        SMT_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (prep_ms) prep_ms[k] = a;
+        if (cost_ms) cost_ms[k] = b;
+    }
+    *count = (int)n;
+    return SMT_OK;
+}
+
+SMT_API int smt_wta(const float *vol, int H, int W, int D, float *disp, void *stream)
+{
+    if (!vol || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    const int N = H * W;
+    dim3 grid((N + 3) / 4);
+    const int C = (D + 63) / 64;
+    hipStream_t st = smt_stream(stream);
+    switch (C) {
+    case 1: hipLaunchKernelGGL(k_wta<1>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    case 2: hipLaunchKernelGGL(k_wta<2>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    case 3: hipLaunchKernelGGL(k_wta<3>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    default: hipLaunchKernelGGL(k_wta<4>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    }
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}

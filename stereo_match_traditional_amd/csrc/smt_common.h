@@ -1,0 +1,62 @@
+// Shared host/device helpers for libsmt_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/smt.h"
+
+#define SMT_API extern "C" __attribute__((visibility("default")))
+
+extern thread_local int g_smt_last_hip;
+
+#define SMT_HIP(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            g_smt_last_hip = (int)_e;                      \
+            return SMT_ERR_HIP;                            \
+        }                                                  \
+    } while (0)
+
+#define SMT_LAUNCH_CHECK()                                 \
+    do {                                                   \
+        hipError_t _e = hipGetLastError();                 \
+        if (_e != hipSuccess) {                            \
+            g_smt_last_hip = (int)_e;                      \
+            return SMT_ERR_HIP;                            \
+        }                                                  \
+    } while (0)
+
+static inline hipStream_t smt_stream(void *s) { return (hipStream_t)s; }
+
+#ifdef __HIPCC__
+constexpr int WAVE = 64;
+
+// std::min / std::max semantics of the reference (returns the FIRST argument on ties and
+// for the +0/-0 pair), kept instead of fminf so that signs of zero cannot diverge.
+__device__ __forceinline__ float ref_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float ref_max(float a, float b) { return (a < b) ? b : a; }
+
+// Wave-wide minimum of non-NaN floats (all 64 lanes active).
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+// First-strict-minimum WTA across a wave whose lanes hold candidates in increasing-d
+// order: (v, d) = this lane's first local minimum.  Returns the winning d in every lane.
+__device__ __forceinline__ int wave_argmin_first(float v, int d)
+{
+    const float m = wave_min_f32(v);
+    const unsigned long long b = __ballot(v == m);
+    const int first = __ffsll((long long)b) - 1;
+    return __shfl(d, first, WAVE);
+}
+#endif
