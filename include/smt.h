@@ -114,6 +114,10 @@ int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, 
  * destroy. view = SMT_VIEW_LEFT or SMT_VIEW_RIGHT. */
 int smt_adcensus_volume(smt_adcensus *h, int view, float **vol);
 
+/* Test hook: D that are multiples of 64 normally take the register-window kernel; on != 0
+ * routes them through the general (any D) kernel as well so both stay covered. */
+int smt_adcensus_force_generic(smt_adcensus *h, int on);
+
 /* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen so far was not an
  * integer in 0..255 (then the volumes are unspecified), else SMT_OK. */
 int smt_adcensus_status(smt_adcensus *h);

@@ -129,6 +129,9 @@ class AD_Census:
     def status(self):
         check(lib().smt_adcensus_status(self._h), "smt_adcensus_status")
 
+    def force_generic(self, on=True):
+        check(lib().smt_adcensus_force_generic(self._h, int(on)), "smt_adcensus_force_generic")
+
     def timing(self, enable=True):
         check(lib().smt_adcensus_timing(self._h, int(enable)), "smt_adcensus_timing")
 

@@ -250,6 +250,140 @@ __global__ void __launch_bounds__(NT) k_cost(int H, int W, int D, Tables T, int 
     }
 }
 
+// ---- fast path: D == 64*C ---------------------------------------------------------------
+// Same mapping (one wave per pixel, lane l owns d = l*C..l*C+C-1) with the instruction count
+// cut down: VIEW is a template parameter; each wave walks FPW CONSECUTIVE pixels so that
+// a lane's C ext operands form a register sliding window (one new LDS entry per pixel
+// instead of C); values are staged pre-multiplied by 4 so v_sad_u16 yields the lutA byte
+// address directly; the WTA is a DPP min over the cost bit patterns (costs are >= +0, so
+// uint order == float order) + ballot + scalar pick, no LDS round trips; the FPW winners
+// are collected one per lane and stored once per wave.
+constexpr int FTJ = 128;          // pixels per workgroup
+constexpr int FPW = FTJ / 4;      // consecutive pixels per wave
+
+struct __attribute__((aligned(16))) Anchor { uint64_t cen, mask; };
+
+template <int C, int VIEW>
+__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float *__restrict__ vol,
+                                                  float *__restrict__ disp)
+{
+    constexpr int D = 64 * C;
+    constexpr int NX = FTJ + D;
+    __shared__ Anchor s_anc[FTJ];
+    __shared__ uint64_t s_cenx[NX];
+    __shared__ float s_lut[320];
+    __shared__ uint16_t s_valx[NX];
+    __shared__ uint16_t s_vala[FTJ];
+
+    const int i = blockIdx.y;
+    const int j0 = blockIdx.x * FTJ;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    {
+        const uint64_t *cenX = T.cenX[VIEW] + (size_t)i * T.WX;
+        const uint8_t *extv = T.u8[VIEW ^ 1] + (size_t)i * W;
+        const uint8_t *ancv = T.u8[VIEW] + (size_t)i * W;
+        const int xbase = (VIEW == 0) ? (j0 - (D - 1)) : j0;
+        for (int e = tid; e < NX; e += NT) {
+            const int x = xbase + e;
+            int xc, xv;
+            if (VIEW == 0) {
+                xc = x < -3 ? -3 : (x > W - 1 ? W - 1 : x);
+                xv = xc < 0 ? 0 : xc;
+                xc += 3;
+            } else {
+                xc = x > W + 3 ? W + 3 : x;
+                xv = x > W - 1 ? W - 1 : x;
+            }
+            s_cenx[e] = cenX[xc];
+            s_valx[e] = (uint16_t)(4u * extv[xv]);
+        }
+        for (int e = tid; e < FTJ; e += NT) {
+            int j = j0 + e;
+            if (j > W - 1) j = W - 1;
+            Anchor a;
+            a.cen = T.cenA[VIEW][(size_t)i * W + j];
+            a.mask = T.mask[(size_t)i * W + j];
+            s_anc[e] = a;
+            s_vala[e] = (uint16_t)(4u * ancv[j]);
+        }
+        for (int e = tid; e < 320; e += NT) s_lut[e] = T.lut[e];
+    }
+    __syncthreads();
+
+    const int p0 = wid * FPW;
+    const int dl = lane * C;
+    // ext entry of (pixel p, hypothesis dl+k):  VIEW 0: p + (D-1) - dl - k ;  VIEW 1: p + dl + k
+    const int e0 = (VIEW == 0) ? (p0 + (D - 1) - dl) : (p0 + dl);
+    uint64_t wc[C];
+    unsigned wv[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const int e = (VIEW == 0) ? (e0 - k) : (e0 + k);
+        wc[k] = s_cenx[e];
+        wv[k] = s_valx[e];
+    }
+    const char *lutA = (const char *)s_lut;
+    const float *lutC = s_lut + 256;
+    float *out = vol + ((size_t)i * W + j0 + p0) * D + dl;
+    int res = 0;
+    const int npx = min(FPW, W - (j0 + p0));                 // uniform; may be <= 0
+
+    for (int q = 0; q < npx; q++) {
+        const int p = p0 + q;
+        const Anchor a = s_anc[p];
+        const unsigned va = s_vala[p];
+        // the entry that enters the window at the next pixel (always inside the staged range)
+        const int en = (VIEW == 0) ? (e0 + q + 1) : (e0 + q + C);
+        const uint64_t nc = s_cenx[en];
+        const unsigned nv = s_valx[en];
+
+        float c[C];
+        unsigned key[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const uint64_t x = (a.cen ^ wc[k]) & a.mask;
+            const int hd = __popcll(x);
+            const unsigned ad4 = __builtin_amdgcn_sad_u16(va, wv[k], 0u);   // 4*|va - vx|
+            c[k] = *(const float *)(lutA + ad4) + lutC[hd];
+            key[k] = __float_as_uint(c[k]);
+        }
+        vecf<C> pk;
+#pragma unroll
+        for (int k = 0; k < C; k++) pk.v[k] = c[k];
+        *reinterpret_cast<vecf<C> *>(out) = pk;
+        out += D;
+
+        if (disp) {
+            unsigned ml = key[0];
+#pragma unroll
+            for (int k = 1; k < C; k++) ml = min(ml, key[k]);
+            const unsigned m = wave_min_u32(ml);
+            const unsigned long long b = __ballot(ml == m);
+            const int first = __builtin_ctzll(b);
+            int kk = C - 1;
+#pragma unroll
+            for (int k = C - 2; k >= 0; k--)
+                if ((unsigned)__builtin_amdgcn_readlane((int)key[k], first) == m) kk = k;
+            const int wd = first * C + kk;                   // wave-uniform
+            res = (lane == q) ? wd : res;
+        }
+        // slide the window
+        if (VIEW == 0) {
+#pragma unroll
+            for (int k = C - 1; k >= 1; k--) { wc[k] = wc[k - 1]; wv[k] = wv[k - 1]; }
+            wc[0] = nc; wv[0] = nv;
+        } else {
+#pragma unroll
+            for (int k = 0; k < C - 1; k++) { wc[k] = wc[k + 1]; wv[k] = wv[k + 1]; }
+            wc[C - 1] = nc; wv[C - 1] = nv;
+        }
+    }
+    if (disp && lane < npx) disp[(size_t)i * W + j0 + p0 + lane] = (float)res;
+}
+
 // generic WTA over an existing volume: one wave per pixel.
 template <int C>
 __global__ void __launch_bounds__(NT) k_wta(const float *__restrict__ vol, int N, int D,
@@ -286,6 +420,7 @@ struct smt_adcensus {
     Tables T;
     hipEvent_t *ev;      // SMT_TIMING_SLOTS * 3, lazily created
     bool timing;
+    bool force_generic;  // test hook: route D%64==0 through the generic kernel too
     long n_timed;        // pairs recorded since timing was (re-)enabled
 };
 
@@ -352,7 +487,7 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     smt_adcensus *h = new (std::nothrow) smt_adcensus();
     if (!h) return SMT_ERR_ALLOC;
     h->H = H; h->W = W; h->D = D; h->sigmaC = sigmaC; h->sigmaS = sigmaS;
-    h->stream = nullptr; h->timing = false; h->ev = nullptr; h->n_timed = 0;
+    h->stream = nullptr; h->timing = false; h->force_generic = false; h->ev = nullptr; h->n_timed = 0;
     const size_t N = (size_t)H * W, V = N * D;
     const int WX = W + 4;
     h->T.WX = WX;
@@ -416,6 +551,18 @@ static void launch_cost(smt_adcensus *h, int view0, int nviews, float *d0, float
                        view0, h->vol[0], h->vol[1], d0, d1);
 }
 
+template <int C>
+static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
+{
+    dim3 grid((h->W + FTJ - 1) / FTJ, h->H);
+    if (views & SMT_VIEW_LEFT)
+        hipLaunchKernelGGL((k_cost_fast<C, 0>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->T,
+                           h->vol[0], dL);
+    if (views & SMT_VIEW_RIGHT)
+        hipLaunchKernelGGL((k_cost_fast<C, 1>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->T,
+                           h->vol[1], dR);
+}
+
 static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int views, float *dL,
                          float *dR)
 {
@@ -432,11 +579,11 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
     const int C = (D + 63) / 64;
     const bool full = (D % 64) == 0;
-    switch (C * 2 + (full ? 1 : 0)) {
-    case 3: launch_cost<1, true>(h, view0, nviews, dL, dR); break;
-    case 5: launch_cost<2, true>(h, view0, nviews, dL, dR); break;
-    case 7: launch_cost<3, true>(h, view0, nviews, dL, dR); break;
-    case 9: launch_cost<4, true>(h, view0, nviews, dL, dR); break;
+    switch (C * 2 + ((full && !h->force_generic) ? 1 : 0)) {
+    case 3: launch_fast<1>(h, views, dL, dR); break;
+    case 5: launch_fast<2>(h, views, dL, dR); break;
+    case 7: launch_fast<3>(h, views, dL, dR); break;
+    case 9: launch_fast<4>(h, views, dL, dR); break;
     case 2: launch_cost<1, false>(h, view0, nviews, dL, dR); break;
     case 4: launch_cost<2, false>(h, view0, nviews, dL, dR); break;
     case 6: launch_cost<3, false>(h, view0, nviews, dL, dR); break;
@@ -482,6 +629,13 @@ SMT_API int smt_adcensus_status(smt_adcensus *h)
     SMT_HIP(hipMemcpyAsync(&f, h->T.flag, 4, hipMemcpyDeviceToHost, h->stream));
     SMT_HIP(hipStreamSynchronize(h->stream));
     return f ? SMT_ERR_DOMAIN : SMT_OK;
+}
+
+SMT_API int smt_adcensus_force_generic(smt_adcensus *h, int on)
+{
+    if (!h) return SMT_ERR_ARG;
+    h->force_generic = on != 0;
+    return SMT_OK;
 }
 
 SMT_API int smt_adcensus_timing(smt_adcensus *h, int enable)

@@ -50,6 +50,31 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return v;
 }
 
+// ---- DPP wave reductions (gfx9 row_bcast forms; all 64 lanes must be active) ------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    // old = identity of umin so the DPP combiner can fold the move into v_min_u32_dpp
+    return (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// minimum over the wave of unsigned keys, returned wave-uniform (SGPR).
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+    v = min(v, dpp_u32<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+    v = min(v, dpp_u32<0x141, 0xF>(v));   // row_half_mirror
+    v = min(v, dpp_u32<0x140, 0xF>(v));   // row_mirror      -> every lane holds its row's min
+    v = min(v, dpp_u32<0x142, 0xA>(v));   // row_bcast15 into rows 1,3
+    v = min(v, dpp_u32<0x143, 0xC>(v));   // row_bcast31 into rows 2,3 -> lane 63 holds the min
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// order-preserving map float -> uint32 (handles negatives; NaNs are not ordered)
+__device__ __forceinline__ unsigned f32_key(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
 // First-strict-minimum WTA across a wave whose lanes hold candidates in increasing-d
 // order: (v, d) = this lane's first local minimum.  Returns the winning d in every lane.
 __device__ __forceinline__ int wave_argmin_first(float v, int d)

@@ -23,12 +23,13 @@ CASES = [
 ]
 
 
-def _run(smt, L, R, D, sc=10.0, ss=30.0):
+def _run(smt, L, R, D, sc=10.0, ss=30.0, generic=False):
     H, W = L.shape
     dev = torch.device("cuda:0")
     Lf = torch.from_numpy(L.astype(np.float32)).to(dev)
     Rf = torch.from_numpy(R.astype(np.float32)).to(dev)
     adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, sc, ss)
+    adc.force_generic(generic)
     dl = torch.full((H, W), -1.0, device=dev)
     dr = torch.full((H, W), -1.0, device=dev)
     adc.ComputeBoth(dl, dr)
@@ -39,10 +40,20 @@ def _run(smt, L, R, D, sc=10.0, ss=30.0):
     return out
 
 
+CASES += [
+    (7, 300, 64, 12, False),    # several workgroups per row + ragged tail (fast kernel: 128 px/WG)
+    (6, 257, 192, 13, True),
+    (5, 129, 256, 14, False),
+]
+
+
+@pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("H,W,D,seed,noise", CASES)
-def test_adcensus_bit_exact(smt, O, H, W, D, seed, noise):
+def test_adcensus_bit_exact(smt, O, H, W, D, seed, noise, generic):
+    if generic and D % 64:
+        pytest.skip("already the general kernel")
     L, R = O.synth_pair(H, W, D, seed, noise)
-    vl, vr, dl, dr = _run(smt, L, R, D)
+    vl, vr, dl, dr = _run(smt, L, R, D, generic=generic)
     ol = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
     orr = O.adcensus_view(L, R, D, 10.0, 30.0, 1)
     assert np.array_equal(vl.view(np.uint32), ol.view(np.uint32)), "left volume differs"
