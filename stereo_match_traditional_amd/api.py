@@ -11,7 +11,10 @@ import torch
 from . import _lib
 from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
-__all__ = ["AD_Census", "wta", "current_stream_ptr"]
+__all__ = ["AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
+           "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
+           "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
+           "AdaptiveSupportWeight", "asw_CrossCheckDiaparity"]
 
 
 def current_stream_ptr():
@@ -166,3 +169,330 @@ def wta(vol, disp=None):
     _dev(disp, torch.float32, (H, W), "disp")
     check(lib().smt_wta(_ptr(vol), H, W, D, _ptr(disp), current_stream_ptr()), "smt_wta")
     return disp
+
+
+# ======================================================================================
+# CrossArmAggregation  (AD-CensusV1/CrossArm.h:9-36) + CBLSM.h arms / costAggregationV5
+# ======================================================================================
+class CrossArmAggregation:
+    """Initialize(row, col, leftImage, rightImage, tao, dispRange) -- the two float image
+    pointers are stored but never used by the reference (CrossArm.cpp:10-11) and are
+    dropped here.  `style="cblsm"` selects the CBLSM.cpp:28-32 constants (tau=25, by-value
+    threshold, no right-arm stride bug)."""
+
+    def __init__(self):
+        self._h = None
+
+    def Initialize(self, row, col, tao, dispRange, device=None, style="adcensus", quirks=None,
+                   sec_length=17, max_length=34, tau_low=6):
+        self.close()
+        self.row, self.col, self.dispRange = int(row), int(col), int(dispRange)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        p = _lib.CrossArmParams()
+        if style == "cblsm":
+            lib().smt_crossarm_cblsm_params(C.byref(p))
+        else:
+            lib().smt_crossarm_default_params(C.byref(p))
+        p.tau, p.tau_low, p.sec_length, p.max_length = int(tao), tau_low, sec_length, max_length
+        if quirks is not None:
+            p.quirks = quirks
+        h = C.c_void_p()
+        check(lib().smt_crossarm_create(self.row, self.col, self.dispRange, C.byref(p), C.byref(h)),
+              "smt_crossarm_create")
+        self._h = h
+        return self
+
+    def _bind(self):
+        check(lib().smt_crossarm_set_stream(self._h, current_stream_ptr()), "smt_crossarm_set_stream")
+
+    def ComputeArmLengths(self, Image):
+        """ComputeLeftArmLength, ComputeRightArmLength, ComputeTopArmLength,
+        ComputeButtonArmLength (CrossArm.cpp:147-598) in main.cpp:69-72's order.
+        Image: uint8 [row][col] or [row][col][3]."""
+        ch = 1 if Image.dim() == 2 else int(Image.shape[2])
+        _dev(Image, torch.uint8, (self.row, self.col) if ch == 1 else (self.row, self.col, ch), "Image")
+        self._bind()
+        check(lib().smt_crossarm_arms(self._h, _ptr(Image), ch), "smt_crossarm_arms")
+
+    def arm_maps(self):
+        ps = [C.c_void_p() for _ in range(4)]
+        check(lib().smt_crossarm_arm_maps(self._h, *[C.byref(p) for p in ps]), "smt_crossarm_arm_maps")
+        return [_view_of(p.value, (self.row, self.col), torch.int32, self.device) for p in ps]
+
+    def _agg(self, dispVolume, aggregatedCostVolume, order, disp):
+        shp = (self.row, self.col, self.dispRange)
+        _dev(dispVolume, torch.float32, shp, "dispVolume")
+        _dev(aggregatedCostVolume, torch.float32, shp, "aggregatedCostVolume")
+        if disp is not None:
+            _dev(disp, torch.float32, (self.row, self.col), "disp")
+        self._bind()
+        check(lib().smt_crossarm_aggregate(self._h, _ptr(dispVolume), _ptr(aggregatedCostVolume), order,
+                                           _ptr(disp)), "smt_crossarm_aggregate")
+
+    def AggregationVertical(self, dispVolume, aggregatedCostVolume, disp=None):
+        """CrossArm.cpp:60-102 (+ fused WTA :33-57 when disp is given)."""
+        self._agg(dispVolume, aggregatedCostVolume, 0, disp)
+
+    def costAggregationV5(self, dispvolume, CostVolume, disp=None):
+        """CBLSM.h:1179-1224 (row-major add order)."""
+        self._agg(dispvolume, CostVolume, 1, disp)
+
+    def WTA(self, AggredCostVolume, disp):
+        wta(AggredCostVolume, disp)
+
+    def status(self):
+        check(lib().smt_crossarm_status(self._h), "smt_crossarm_status")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            lib().smt_crossarm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cblsm_ComputeAD(L, R, dispRange, view=VIEW_LEFT, out=None):
+    """CBLSM.h:327-353 (view left) / :355-381 (view right): uchar images -> float AD volume."""
+    H, W = L.shape
+    _dev(L, torch.uint8, (H, W), "L")
+    _dev(R, torch.uint8, (H, W), "R")
+    if out is None:
+        out = torch.empty((H, W, dispRange), dtype=torch.float32, device=L.device)
+    check(lib().smt_cblsm_ad(_ptr(L), _ptr(R), H, W, dispRange, view, _ptr(out), current_stream_ptr()),
+          "smt_cblsm_ad")
+    return out
+
+
+# ======================================================================================
+# ScanlineOptimizer  (AD-CensusV1/ScanlineOptimizer.h:8-34)
+# ======================================================================================
+class ScanlineOptimizer:
+    def __init__(self):
+        self._h = None
+
+    def Initialize(self, row, col, dispRange, p1, p2, device=None):
+        """:66-79 (the costVolume pointer argument is re-passed to ScanLine anyway)."""
+        self.close()
+        self.row, self.col, self.dispRange = int(row), int(col), int(dispRange)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        h = C.c_void_p()
+        check(lib().smt_scanline_create(self.row, self.col, self.dispRange, int(p1), int(p2), C.byref(h)),
+              "smt_scanline_create")
+        self._h = h
+        self._processed = None
+        return self
+
+    def ScanLine(self, costVolume, Image, out=None, disp=None):
+        """:104-128; returns `_ProcessedVolume`.  Image = float32 gray guidance."""
+        shp = (self.row, self.col, self.dispRange)
+        _dev(costVolume, torch.float32, shp, "costVolume")
+        _dev(Image, torch.float32, (self.row, self.col), "Image")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=costVolume.device)
+        _dev(out, torch.float32, shp, "out")
+        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr()), "smt_scanline_set_stream")
+        check(lib().smt_scanline_run(self._h, _ptr(costVolume), _ptr(Image), _ptr(out), _ptr(disp)),
+              "smt_scanline_run")
+        self._processed = out
+        return out
+
+    def ScanPass(self, costVolume, Image, which):
+        """One path volume: 'left' (ScanLineLeftRight isLeft=true, :130-192), 'right', 'up'
+        (ScanLineUpDown isUp=true, :194-253), 'down'."""
+        pass_id = {"left": 0, "right": 1, "up": 2, "down": 3}[which]
+        out = torch.empty_like(costVolume)
+        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr()), "smt_scanline_set_stream")
+        check(lib().smt_scanline_pass(self._h, _ptr(costVolume), _ptr(Image), pass_id, _ptr(out)),
+              "smt_scanline_pass")
+        return out
+
+    def WTA(self, disp):
+        """:40-64 over `_ProcessedVolume`."""
+        wta(self._processed, disp)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            lib().smt_scanline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ======================================================================================
+# LeftRightConsistency  (AD-CensusV1/PostProcessing.h:72-135)
+# ======================================================================================
+def LeftRightConsistency(col, row, gate, leftDisp, rightDisp, want_lists=False):
+    """In place on leftDisp (+inf = invalid).  Returns (cls uint8 [row][col], n_occlusion,
+    n_mismatch[, occlusions, mismatches]); the lists are (row, col) pairs in the
+    reference's row-major order."""
+    _dev(leftDisp, torch.float32, (row, col), "leftDisp")
+    _dev(rightDisp, torch.float32, (row, col), "rightDisp")
+    cls = torch.empty((row, col), dtype=torch.uint8, device=leftDisp.device)
+    counts = torch.zeros(2, dtype=torch.int32, device=leftDisp.device)
+    check(lib().smt_lrcheck(_ptr(leftDisp), _ptr(rightDisp), row, col, int(gate), _ptr(cls), _ptr(counts),
+                            current_stream_ptr()), "smt_lrcheck")
+    n = counts.cpu().tolist()
+    if not want_lists:
+        return cls, n[0], n[1]
+    import numpy as np
+    ch = np.ascontiguousarray(cls.cpu().numpy())
+    occ = np.empty((row * col, 2), np.int32)
+    mis = np.empty((row * col, 2), np.int32)
+    no, nm = C.c_int(), C.c_int()
+    check(lib().smt_lrcheck_lists(ch.ctypes.data_as(C.c_void_p), row, col, occ.ctypes.data_as(C.c_void_p),
+                                  C.byref(no), mis.ctypes.data_as(C.c_void_p), C.byref(nm)), "smt_lrcheck_lists")
+    return cls, n[0], n[1], occ[:no.value], mis[:nm.value]
+
+
+# ======================================================================================
+# CrossAggregator  (CBLSM/cross_aggregator.h:27-113)
+# ======================================================================================
+class CrossAggregator:
+    def __init__(self):
+        self._h = None
+
+    def Initialize(self, width, height, min_disparity, max_disparity, device=None):
+        """:19-58; returns False where the reference does."""
+        self.close()
+        self.width, self.height = int(width), int(height)
+        self.disp_range = int(max_disparity) - int(min_disparity)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        h = C.c_void_p()
+        rc = lib().smt_crossagg_create(self.width, self.height, self.disp_range, C.byref(h))
+        if rc == -1:
+            return False
+        check(rc, "smt_crossagg_create")
+        self._h = h
+        return True
+
+    def SetData(self, img_left, img_right, cost_init):
+        """:60-65 (img_right is stored but never read by the reference)."""
+        self._img = _dev(img_left, torch.uint8, (self.height, self.width, 3), "img_left")
+        self._cost = _dev(cost_init, torch.float32, (self.height, self.width, self.disp_range), "cost_init")
+
+    def SetParams(self, cross_L1, cross_L2, cross_t1, cross_t2):
+        check(lib().smt_crossagg_set_params(self._h, int(cross_L1), int(cross_L2), int(cross_t1), int(cross_t2)),
+              "smt_crossagg_set_params")
+
+    def Aggregate(self, num_iters):
+        """:89-118; silently does nothing when uninitialised, like the reference (:91-93)."""
+        if self._h is None:
+            return
+        check(lib().smt_crossagg_set_stream(self._h, current_stream_ptr()), "smt_crossagg_set_stream")
+        check(lib().smt_crossagg_aggregate(self._h, _ptr(self._img), _ptr(self._cost), int(num_iters)),
+              "smt_crossagg_aggregate")
+
+    def get_cost_ptr(self):
+        p = C.c_void_p()
+        check(lib().smt_crossagg_cost(self._h, C.byref(p)), "smt_crossagg_cost")
+        return _view_of(p.value, (self.height, self.width, self.disp_range), torch.float32, self.device)
+
+    def get_arms_ptr(self):
+        p = C.c_void_p()
+        check(lib().smt_crossagg_arms(self._h, C.byref(p)), "smt_crossagg_arms")
+        return _view_of(p.value, (self.height, self.width, 4), torch.uint8, self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            lib().smt_crossagg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ======================================================================================
+# Window matchers  (SAD/Sad.h, NCC/NCC.h, ASW/ASW.h)
+# ======================================================================================
+def GetPointDepthLeft(leftimg, rightimg, MaxDisparity, winsize):
+    """Sad.h:96-139.  leftimg/rightimg: uint8 replicate-padded by winsize+1."""
+    return _sad(leftimg, rightimg, MaxDisparity, winsize, VIEW_LEFT)
+
+
+def GetPointDepthRight(leftimg, rightimg, MaxDisparity, winsize):
+    """Sad.h:141-182."""
+    return _sad(leftimg, rightimg, MaxDisparity, winsize, VIEW_RIGHT)
+
+
+def _sad(Lp, Rp, D, winsize, view):
+    w = winsize + 1
+    Hp, Wp = Lp.shape
+    H, W = Hp - 2 * w, Wp - 2 * w
+    _dev(Lp, torch.uint8, (Hp, Wp), "leftimg")
+    _dev(Rp, torch.uint8, (Hp, Wp), "rightimg")
+    disp = torch.empty((H, W), dtype=torch.int32, device=Lp.device)
+    check(lib().smt_sad(_ptr(Lp), _ptr(Rp), H, W, D, winsize, view, _ptr(disp), current_stream_ptr()), "smt_sad")
+    return disp
+
+
+def sad_CrossCheckDiaparity(leftdisp, rightdisp):
+    """Sad.h:184-222 -> (lastdisp int32, cls uint8)."""
+    H, W = leftdisp.shape
+    _dev(leftdisp, torch.int32, (H, W), "leftdisp")
+    _dev(rightdisp, torch.int32, (H, W), "rightdisp")
+    out = torch.empty_like(leftdisp)
+    cls = torch.empty((H, W), dtype=torch.uint8, device=leftdisp.device)
+    check(lib().smt_sad_crosscheck(_ptr(leftdisp), _ptr(rightdisp), H, W, _ptr(out), _ptr(cls),
+                                   current_stream_ptr()), "smt_sad_crosscheck")
+    return out, cls
+
+
+def NCC_algorithem(leftImage, rigthImage, winSize, dispRange, want_cost=False):
+    """NCC.h:69-95.  uint8 [H][W] unpadded images -> int32 disparity (argmax)."""
+    H, W = leftImage.shape
+    _dev(leftImage, torch.uint8, (H, W), "leftImage")
+    _dev(rigthImage, torch.uint8, (H, W), "rigthImage")
+    disp = torch.empty((H, W), dtype=torch.int32, device=leftImage.device)
+    cost = torch.full((H, W, dispRange), float("nan"), dtype=torch.float64, device=leftImage.device) if want_cost else None
+    check(lib().smt_ncc(_ptr(leftImage), _ptr(rigthImage), H, W, dispRange, winSize, _ptr(disp), _ptr(cost),
+                        current_stream_ptr()), "smt_ncc")
+    return (disp, cost) if want_cost else disp
+
+
+def asw_masks(winSize, spaceSigma, colorSigma, device):
+    """getGausssianMask (ASW.h:16-35) + getColorMask (:41-47), host float64 -> device tensors."""
+    import numpy as np
+    side = 2 * winSize + 3
+    sp = np.empty((side, side), np.float64)
+    cm = np.empty(256, np.float64)
+    check(lib().smt_asw_masks(winSize, C.c_double(spaceSigma), C.c_double(colorSigma),
+                              sp.ctypes.data_as(C.c_void_p), cm.ctypes.data_as(C.c_void_p)), "smt_asw_masks")
+    return torch.from_numpy(sp).to(device), torch.from_numpy(cm).to(device)
+
+
+def AdaptiveSupportWeight(leftGray, rightGray, winSize, dispRange, space, color, T, view=VIEW_LEFT, want_cost=False):
+    """ASW.h:329-378 (view left) / :382-431 (view right).  Padded uint8 images."""
+    wins = winSize + 1
+    Hp, Wp = leftGray.shape
+    H, W = Hp - 2 * wins, Wp - 2 * wins
+    _dev(leftGray, torch.uint8, (Hp, Wp), "leftGray")
+    _dev(rightGray, torch.uint8, (Hp, Wp), "rightGray")
+    _dev(space, torch.float64, (2 * winSize + 3, 2 * winSize + 3), "space")
+    _dev(color, torch.float64, (256,), "color")
+    disp = torch.empty((H, W), dtype=torch.float32, device=leftGray.device)
+    cost = torch.empty((H, W, dispRange), dtype=torch.float32, device=leftGray.device) if want_cost else None
+    check(lib().smt_asw(_ptr(leftGray), _ptr(rightGray), H, W, dispRange, winSize, _ptr(space), _ptr(color), int(T),
+                        view, _ptr(disp), _ptr(cost), current_stream_ptr()), "smt_asw")
+    return (disp, cost) if want_cost else disp
+
+
+def asw_CrossCheckDiaparity(leftdisp, rightdisp):
+    """ASW.h:108-145 -> uint8 map (0 = rejected)."""
+    H, W = leftdisp.shape
+    _dev(leftdisp, torch.float32, (H, W), "leftdisp")
+    _dev(rightdisp, torch.float32, (H, W), "rightdisp")
+    out = torch.empty((H, W), dtype=torch.uint8, device=leftdisp.device)
+    check(lib().smt_asw_crosscheck(_ptr(leftdisp), _ptr(rightdisp), H, W, _ptr(out), current_stream_ptr()),
+          "smt_asw_crosscheck")
+    return out

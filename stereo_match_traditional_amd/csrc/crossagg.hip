@@ -1,0 +1,218 @@
+// Cross-based cost aggregation -- replaces class CrossAggregator
+// (CBLSM/cross_aggregator.{h,cpp}, vendored from ethan-li-coding/AD-Census).
+//
+// Arms (FindHorizontalArm / FindVerticalArm, cross_aggregator.cpp:135-269) and support
+// counts (ComputeSupPixelCount, :271-325) are per-pixel work.  AggregateInArms (:327-394)
+// is, per disparity plane, two separable passes of SEQUENTIAL float sums along the arms;
+// the planes are independent, so one wavefront takes one pixel with the disparity axis on
+// its lanes (coalesced 64*C*4-byte taps) and walks the arm in the reference's order
+// (t = -arm .. +arm).  Pass 1 goes cur -> tmp, pass 2 tmp -> cur with the division by the
+// uint16 support count, exactly like vec_cost_tmp_[0/1] and cost_aggr_ per plane.
+#include "smt_common.h"
+#include <new>
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ int col_dist(const uint8_t *a, const uint8_t *b)
+{
+    const int d0 = abs((int)a[0] - (int)b[0]), d1 = abs((int)a[1] - (int)b[1]), d2 = abs((int)a[2] - (int)b[2]);
+    return max(d0, max(d1, d2));                                          // ColorDist, h:78-80
+}
+
+__device__ int ca_arm(const uint8_t *img, int W, int H, int x, int y, int dx, int dy, int L1, int L2,
+                      int t1, int t2)
+{
+    const uint8_t *c0 = img + ((size_t)y * W + x) * 3;
+    const uint8_t *prev = c0;
+    const int lim = L1 < 255 ? L1 : 255;                                  // MAX_ARM_LENGTH
+    int xn = x + dx, yn = y + dy, len = 0;
+    for (int n = 0; n < lim; n++) {
+        if (xn < 0 || xn == W || yn < 0 || yn == H) break;                // :154-163
+        const uint8_t *c = img + ((size_t)yn * W + xn) * 3;
+        const int d1 = col_dist(c, c0);
+        if (d1 >= t1) break;                                              // :169-172
+        if (n > 0 && col_dist(c, prev) >= t1) break;                      // :175-180
+        if (n + 1 > L2 && d1 >= t2) break;                                // :183-187
+        len++;
+        prev = c; xn += dx; yn += dy;
+    }
+    return len;
+}
+
+__global__ void __launch_bounds__(NT) k_ca_arms(const uint8_t *__restrict__ img, int W, int H, int L1, int L2,
+                                                int t1, int t2, uint8_t *__restrict__ arms)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    uchar4 a;
+    a.x = (uint8_t)ca_arm(img, W, H, x, y, -1, 0, L1, L2, t1, t2);
+    a.y = (uint8_t)ca_arm(img, W, H, x, y, +1, 0, L1, L2, t1, t2);
+    a.z = (uint8_t)ca_arm(img, W, H, x, y, 0, -1, L1, L2, t1, t2);
+    a.w = (uint8_t)ca_arm(img, W, H, x, y, 0, +1, L1, L2, t1, t2);
+    reinterpret_cast<uchar4 *>(arms)[p] = a;
+}
+
+// cnt[0]: horizontal first (pass-1 = L+R+1, pass-2 sums those along the vertical arm);
+// cnt[1]: vertical first.  Stored as uint16 like the reference's vectors.
+__global__ void __launch_bounds__(NT) k_ca_counts(const uint8_t *__restrict__ arms, int W, int H,
+                                                  uint16_t *__restrict__ cnt0, uint16_t *__restrict__ cnt1)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    const uchar4 a = reinterpret_cast<const uchar4 *>(arms)[p];
+    int c0 = 0, c1 = 0;
+    for (int t = -(int)a.z; t <= (int)a.w; t++) {
+        const uchar4 q = reinterpret_cast<const uchar4 *>(arms)[(y + t) * W + x];
+        c0 += (uint16_t)((int)q.x + (int)q.y + 1);
+    }
+    for (int t = -(int)a.x; t <= (int)a.y; t++) {
+        const uchar4 q = reinterpret_cast<const uchar4 *>(arms)[y * W + x + t];
+        c1 += (uint16_t)((int)q.z + (int)q.w + 1);
+    }
+    cnt0[p] = (uint16_t)c0;
+    cnt1[p] = (uint16_t)c1;
+}
+
+// one wave per pixel; HORIZ: taps along x with (left,right) else along y with (top,bottom)
+template <int C, bool HORIZ, bool FINAL>
+__global__ void __launch_bounds__(NT) k_ca_pass(const float *__restrict__ src, float *__restrict__ dst, int W, int H,
+                                                int D, const uint8_t *__restrict__ arms,
+                                                const uint16_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= W * H) return;
+    const uchar4 a = reinterpret_cast<const uchar4 *>(arms)[p];
+    const int lo = HORIZ ? -(int)a.x : -(int)a.z;
+    const int hi = HORIZ ? (int)a.y : (int)a.w;
+    const long stride = HORIZ ? 1 : W;
+    const int dl = lane * C;
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.0f;
+    for (int t = lo; t <= hi; t++) {
+        const float *s = src + ((long)p + t * stride) * D + dl;
+#pragma unroll
+        for (int k = 0; k < C; k++)
+            if (dl + k < D) acc[k] += s[k];
+    }
+    float *o = dst + (long)p * D + dl;
+    const float n = FINAL ? (float)cnt[p] : 1.0f;
+#pragma unroll
+    for (int k = 0; k < C; k++)
+        if (dl + k < D) o[k] = FINAL ? acc[k] / n : acc[k];
+}
+
+}  // namespace
+
+struct smt_crossagg {
+    int W, H, D;
+    int L1, L2, t1, t2;
+    hipStream_t stream;
+    float *cur, *tmp;
+    uint8_t *arms;
+    uint16_t *cnt[2];
+};
+
+SMT_API int smt_crossagg_create(int W, int H, int D, smt_crossagg **out)
+{
+    if (!out) return SMT_ERR_ARG;
+    if ((long)W * H <= 0 || W <= 0 || H <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;   // Initialize returns false (:28-31)
+    smt_crossagg *h = new (std::nothrow) smt_crossagg();
+    if (!h) return SMT_ERR_ALLOC;
+    h->W = W; h->H = H; h->D = D;
+    h->L1 = 34; h->L2 = 17; h->t1 = 20; h->t2 = 6;                       // adcensus_types.h:69-70
+    const size_t N = (size_t)W * H;
+    int rc = smt_malloc((void **)&h->cur, N * D * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->tmp, N * D * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->arms, N * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->cnt[0], N * 2);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->cnt[1], N * 2);
+    if (rc != SMT_OK) { smt_crossagg_destroy(h); return rc; }
+    *out = h;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_destroy(smt_crossagg *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    (void)hipFree(h->cur); (void)hipFree(h->tmp); (void)hipFree(h->arms);
+    (void)hipFree(h->cnt[0]); (void)hipFree(h->cnt[1]);
+    delete h;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_set_stream(smt_crossagg *h, void *s)
+{
+    if (!h) return SMT_ERR_ARG;
+    h->stream = smt_stream(s);
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int t2)
+{
+    if (!h || L1 < 0) return SMT_ERR_ARG;
+    h->L1 = L1; h->L2 = L2; h->t1 = t1; h->t2 = t2;
+    return SMT_OK;
+}
+
+template <int C>
+static void ca_iter(smt_crossagg *h, bool hfirst)
+{
+    const int N = h->W * h->H;
+    dim3 grid((N + 3) / 4);
+    const uint16_t *cnt = h->cnt[hfirst ? 0 : 1];
+    if (hfirst) {
+        hipLaunchKernelGGL((k_ca_pass<C, true, false>), grid, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H,
+                           h->D, h->arms, cnt);
+        hipLaunchKernelGGL((k_ca_pass<C, false, true>), grid, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H,
+                           h->D, h->arms, cnt);
+    } else {
+        hipLaunchKernelGGL((k_ca_pass<C, false, false>), grid, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H,
+                           h->D, h->arms, cnt);
+        hipLaunchKernelGGL((k_ca_pass<C, true, true>), grid, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H,
+                           h->D, h->arms, cnt);
+    }
+}
+
+SMT_API int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img, const float *cost_init, int iters)
+{
+    if (!h || !img || !cost_init || iters < 0) return SMT_ERR_ARG;
+    const int N = h->W * h->H;
+    hipLaunchKernelGGL(k_ca_arms, dim3((N + NT - 1) / NT), dim3(NT), 0, h->stream, img, h->W, h->H, h->L1, h->L2,
+                       h->t1, h->t2, h->arms);                            // BuildArms :76-86
+    hipLaunchKernelGGL(k_ca_counts, dim3((N + NT - 1) / NT), dim3(NT), 0, h->stream, h->arms, h->W, h->H,
+                       h->cnt[0], h->cnt[1]);                             // ComputeSupPixelCount
+    SMT_HIP(hipMemcpyAsync(h->cur, cost_init, (size_t)N * h->D * 4, hipMemcpyDeviceToDevice, h->stream)); // :108
+    bool hfirst = true;
+    for (int k = 0; k < iters; k++) {                                     // :111-117
+        switch ((h->D + 63) / 64) {
+        case 1: ca_iter<1>(h, hfirst); break;
+        case 2: ca_iter<2>(h, hfirst); break;
+        case 3: ca_iter<3>(h, hfirst); break;
+        default: ca_iter<4>(h, hfirst); break;
+        }
+        hfirst = !hfirst;
+    }
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_cost(smt_crossagg *h, float **cost)
+{
+    if (!h || !cost) return SMT_ERR_ARG;
+    *cost = h->cur;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_arms(smt_crossagg *h, uint8_t **arms)
+{
+    if (!h || !arms) return SMT_ERR_ARG;
+    *arms = h->arms;
+    return SMT_OK;
+}

@@ -1,0 +1,345 @@
+// Cross-arm lengths + rectangle-mean aggregation -- replaces class CrossArmAggregation
+// (AD-CensusV1/CrossArm.{h,cpp}) and CBLSM.h ArmLength{L,R,Up,Down} / costAggregationV5 /
+// ComputeAD(Right).
+//
+// Arms.  The reference walks pixels row-major with ONE mutable threshold (`_tao`,
+// CrossArm.h:34): it drops from tau to tau_low the first time any arm enters iteration
+// sec+1 and never rises again -- across pixels and (member state) across the four
+// direction calls.  Parallel form, two kernels:
+//   k_arm_flip : per direction, F[dir] = min row-major index of a pixel whose neighbours
+//                1..sec are all inside the image and all within the INITIAL tau (that is
+//                exactly "enters iteration sec+1 while the threshold is still tau":
+//                the flip at CrossArm.cpp:223-225 precedes the bounds test of neighbour
+//                sec+1).
+//   k_arms     : threshold entering direction dir = tau_low if chained and any earlier
+//                direction has F < INF, else tau; pixels before F use it throughout, pixel
+//                F switches to tau_low from k = sec+1, pixels after F use tau_low.
+// ComputeRightArmLength's `col = _row` (CrossArm.cpp:265) is reproduced: iteration and
+// bounds over j < H, store stride H, image reads with the true width.
+//
+// Aggregation.  Sequential float adds in the reference's own order (columns outer / rows
+// inner for AggregationVertical, CrossArm.cpp:88-95; rows outer for costAggregationV5,
+// CBLSM.h:1210-1216), because integral images would change the rounding.  One wavefront
+// spans the disparity axis of a pixel (lane l owns C consecutive d), so every tap is one
+// coalesced 64*C*4-byte read that neighbouring pixels' waves re-read from L2.
+#include "smt_common.h"
+#include <limits.h>
+#include <new>
+
+namespace {
+
+constexpr int NT = 256;
+
+struct ArmCfg {
+    int H, W, ch;
+    int tau, tau_low, sec, maxlen, chain, fix_right;
+};
+
+__device__ __forceinline__ int pix_diff(const uint8_t *img, int ch, int a, int b)
+{
+    if (ch == 1) return abs((int)img[a] - (int)img[b]);
+    int m = 0;
+    for (int c = 0; c < ch; c++) {
+        const int v = abs((int)img[a * ch + c] - (int)img[b * ch + c]);
+        m = v > m ? v : m;
+    }
+    return m;
+}
+
+// direction geometry: returns whether neighbour k of (i,j) is inside, and its coordinates
+__device__ __forceinline__ bool arm_nb(int dir, int i, int j, int k, int H, int colR, int &ni, int &nj)
+{
+    ni = i; nj = j;
+    switch (dir) {
+    case 0: nj = j - k; return nj >= 0;
+    case 1: nj = j + k; return nj < colR;
+    case 2: ni = i - k; return ni >= 0;
+    default: ni = i + k; return ni < H;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img, ArmCfg c, int *flip)
+{
+    const int dir = blockIdx.y;
+    const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= c.H * colR) return;
+    const int i = idx / colR, j = idx - i * colR;
+    bool ok = true;
+    for (int k = 1; k <= c.sec && ok; k++) {
+        int ni, nj;
+        ok = arm_nb(dir, i, j, k, c.H, colR, ni, nj);
+        if (ok) ok = pix_diff(img, c.ch, i * c.W + j, ni * c.W + nj) <= c.tau;
+    }
+    if (ok) atomicMin(&flip[dir], idx);
+}
+
+__global__ void __launch_bounds__(NT) k_arms(const uint8_t *__restrict__ img, ArmCfg c,
+                                             const int *__restrict__ flip, int *armL, int *armR,
+                                             int *armT, int *armB)
+{
+    const int dir = blockIdx.y;
+    const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= c.H * colR) return;
+    const int i = idx / colR, j = idx - i * colR;
+
+    int tau_in = c.tau;
+    if (c.chain)
+        for (int e = 0; e < dir; e++)
+            if (flip[e] != INT_MAX) tau_in = c.tau_low;
+    const int F = flip[dir];
+    const int tauA = (tau_in == c.tau && idx <= F) ? c.tau : c.tau_low;   // k <= sec
+    const int tauB = c.tau_low;                                           // k  > sec
+
+    bool far;
+    switch (dir) {
+    case 0: far = (j - 1 >= 1); break;
+    case 1: far = (j + 1 < colR - 1); break;
+    case 2: far = (i - 1 >= 1); break;
+    default: far = (i + 1 < c.H - 1); break;
+    }
+    int saved = 0;
+    for (int k = 1;; k++) {
+        saved = k - 1;
+        if (k > c.sec && k > c.maxlen) break;
+        int ni, nj;
+        if (!arm_nb(dir, i, j, k, c.H, colR, ni, nj)) break;
+        const int tau = (k > c.sec) ? tauB : tauA;
+        if (pix_diff(img, c.ch, i * c.W + j, ni * c.W + nj) > tau) {
+            if (far && saved < 1) saved = 1;
+            break;
+        }
+    }
+    int *out = dir == 0 ? armL : dir == 1 ? armR : dir == 2 ? armT : armB;
+    out[(size_t)i * colR + j] = saved;
+}
+
+template <int C> struct vecf;
+template <> struct vecf<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
+template <> struct vecf<3> { float v[3]; };
+template <> struct __attribute__((aligned(16))) vecf<4> { float v[4]; };
+
+// one wave per pixel; lane owns d = lane*C .. lane*C+C-1 (masked when >= D)
+template <int C, int ORDER>
+__global__ void __launch_bounds__(NT) k_aggregate(const float *__restrict__ vin, float *__restrict__ vout,
+                                                  int H, int W, int D, const int *__restrict__ armL,
+                                                  const int *__restrict__ armR, const int *__restrict__ armT,
+                                                  const int *__restrict__ armB, float *__restrict__ disp,
+                                                  int *ub_flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = H * W;
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= N) return;
+    const int i = p / W, j = p - i * W;
+    const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
+    const int dl = lane * C;
+    const bool full = (dl + C <= D);
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.0f;
+    bool ub = false;
+
+    auto tap = [&](int t, int l) {
+        const int idx = (i + t) * W + j + l;            // flat, wraps across row ends like the reference
+        if (idx < 0 || idx >= N) { ub = true; return; } // reference reads outside the plane: UB -> 0
+        const float *src = vin + (size_t)idx * D + dl;
+        if (full) {
+            const vecf<C> x = *reinterpret_cast<const vecf<C> *>(src);
+#pragma unroll
+            for (int k = 0; k < C; k++) acc[k] = acc[k] + x.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+                if (dl + k < D) acc[k] = acc[k] + src[k];
+        }
+    };
+    if (ORDER == 0) {
+        for (int l = -Ll; l <= Rr; l++)
+            for (int t = -up; t <= dn; t++) tap(t, l);
+    } else {
+        for (int t = -up; t <= dn; t++)
+            for (int l = -Ll; l <= Rr; l++) tap(t, l);
+    }
+    const float cnt = (float)((Ll + Rr + 1) * (up + dn + 1));
+    float best = INFINITY; int bk = 0;
+    float *dst = vout + (size_t)p * D + dl;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        acc[k] = acc[k] / cnt;
+        if (dl + k < D) {
+            dst[k] = acc[k];
+            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
+        }
+    }
+    if (ub && lane == 0) atomicOr(ub_flag, 1);
+    if (disp) {
+        if (dl >= D) best = INFINITY;
+        const int wd = wave_argmin_first(best, dl + bk);
+        if (lane == 0) disp[p] = (float)wd;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_cblsm_ad(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R,
+                                                 int H, int W, int D, int view, float *__restrict__ vol)
+{
+    const size_t k = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t V = (size_t)H * W * D;
+    if (k >= V) return;
+    const int d = (int)(k % D);
+    const size_t p = k / D;
+    const int j = (int)(p % W);
+    const size_t row = p - j;
+    int a, b;
+    if (view == 0) {                 // CBLSM.h:340-349: copy d-1 == clamp j-d at 0
+        const int x = j - d < 0 ? 0 : j - d;
+        a = L[p]; b = R[row + x];
+    } else {                         // CBLSM.h:368-377
+        const int x = j + d >= W ? W - 1 : j + d;
+        a = L[row + x]; b = R[p];
+    }
+    vol[k] = (float)abs(a - b);
+}
+
+}  // namespace
+
+struct smt_crossarm {
+    int H, W, D;
+    smt_crossarm_params P;
+    hipStream_t stream;
+    int *arm[4];
+    int *flip;     // 4 flip indices + 1 UB flag
+    bool have_arms;
+};
+
+SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
+{
+    if (!p) return;
+    p->tau = 30; p->tau_low = 6; p->sec_length = 17; p->max_length = 34; p->chain_tau = 1; p->quirks = 0;
+}
+SMT_API void smt_crossarm_cblsm_params(smt_crossarm_params *p)
+{
+    if (!p) return;
+    p->tau = 25; p->tau_low = 6; p->sec_length = 17; p->max_length = 34; p->chain_tau = 0;
+    p->quirks = SMT_QUIRK_FIX_RIGHT_ARM_STRIDE;
+}
+
+SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out)
+{
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    smt_crossarm *h = new (std::nothrow) smt_crossarm();
+    if (!h) return SMT_ERR_ALLOC;
+    h->H = H; h->W = W; h->D = D;
+    if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
+    if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
+    int rc = SMT_OK;
+    for (int k = 0; k < 4 && rc == SMT_OK; k++) rc = smt_malloc((void **)&h->arm[k], (size_t)H * W * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->flip, 8 * 4);
+    if (rc != SMT_OK) { smt_crossarm_destroy(h); return rc; }
+    if (hipMemset(h->flip, 0, 32) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
+    *out = h;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_destroy(smt_crossarm *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    for (int k = 0; k < 4; k++) (void)hipFree(h->arm[k]);
+    (void)hipFree(h->flip);
+    delete h;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_set_stream(smt_crossarm *h, void *s)
+{
+    if (!h) return SMT_ERR_ARG;
+    h->stream = smt_stream(s);
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
+{
+    if (!h || !img || (channels != 1 && channels != 3)) return SMT_ERR_ARG;
+    const bool fix = (h->P.quirks & SMT_QUIRK_FIX_RIGHT_ARM_STRIDE) != 0;
+    // with the stride bug the reference reads image columns up to H-1+max_length-ish of a
+    // W-wide row: undefined for portrait images
+    if (!fix && h->H > h->W) return SMT_ERR_REF_UB;
+    ArmCfg c{h->H, h->W, channels, h->P.tau, h->P.tau_low, h->P.sec_length, h->P.max_length,
+             h->P.chain_tau, fix ? 1 : 0};
+    const size_t N = (size_t)h->H * h->W;
+    // `new int[col*row]()` zero-initialises every map on each Initialize (CrossArm.cpp:14-17);
+    // with the stride bug most of rightLength stays 0.
+    for (int k = 0; k < 4; k++) SMT_HIP(hipMemsetAsync(h->arm[k], 0, N * 4, h->stream));
+    static const int init[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    SMT_HIP(hipMemcpyAsync(h->flip, init, 16, hipMemcpyHostToDevice, h->stream));
+    dim3 grid((unsigned)((N + NT - 1) / NT), 4);
+    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip);
+    hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
+                       h->arm[2], h->arm[3]);
+    SMT_LAUNCH_CHECK();
+    h->have_arms = true;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_arm_maps(smt_crossarm *h, int **l, int **r, int **t, int **b)
+{
+    if (!h) return SMT_ERR_ARG;
+    if (l) *l = h->arm[0];
+    if (r) *r = h->arm[1];
+    if (t) *t = h->arm[2];
+    if (b) *b = h->arm[3];
+    return SMT_OK;
+}
+
+template <int ORDER>
+static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *disp)
+{
+    const int N = h->H * h->W;
+    dim3 grid((N + 3) / 4);
+    const int C = (h->D + 63) / 64;
+    int *ub = h->flip + 4;
+#define SMT_AGG(CC)                                                                                   \
+    hipLaunchKernelGGL((k_aggregate<CC, ORDER>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub)
+    switch (C) {
+    case 1: SMT_AGG(1); break;
+    case 2: SMT_AGG(2); break;
+    case 3: SMT_AGG(3); break;
+    default: SMT_AGG(4); break;
+    }
+#undef SMT_AGG
+}
+
+SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vout, int order, float *disp)
+{
+    if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
+    if (!h->have_arms) return SMT_ERR_STATE;
+    if (order == 0) launch_agg<0>(h, vin, vout, disp);
+    else launch_agg<1>(h, vin, vout, disp);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_status(smt_crossarm *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    int f = 0;
+    SMT_HIP(hipMemcpyAsync(&f, h->flip + 4, 4, hipMemcpyDeviceToHost, h->stream));
+    SMT_HIP(hipStreamSynchronize(h->stream));
+    return f ? SMT_ERR_REF_UB : SMT_OK;
+}
+
+SMT_API int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int view, float *vol,
+                         void *stream)
+{
+    if (!L || !R || !vol || H <= 0 || W <= 0 || D <= 0 || (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT))
+        return SMT_ERR_ARG;
+    const size_t V = (size_t)H * W * D;
+    hipLaunchKernelGGL(k_cblsm_ad, dim3((unsigned)((V + NT - 1) / NT)), dim3(NT), 0, smt_stream(stream), L, R,
+                       H, W, D, view == SMT_VIEW_LEFT ? 0 : 1, vol);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}

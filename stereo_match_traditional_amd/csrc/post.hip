@@ -1,0 +1,137 @@
+// Consistency checks on disparity maps -- replaces LeftRightConsistency
+// (AD-CensusV1/PostProcessing.h:72-135) and the two CrossCheckDiaparity functions
+// (SAD/Sad.h:184-222, ASW/ASW.h:108-145).
+//
+// LeftRightConsistency runs in place and row-major: when pixel (i,j) is classified it
+// reads leftDisp[i][crl], which has already been overwritten with +inf if crl < j and
+// that pixel was itself rejected (:112 after :125/:130).  Whether a pixel is rejected
+// depends only on the ORIGINAL maps, so the parallel form is: kernel 1 classifies every
+// pixel from the original maps, recomputing "was pixel crl rejected" on the fly for
+// crl < j; kernel 2 writes the +inf values.
+#include "smt_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// true when the reference sets leftDisp[i][x] = inf (or it already was inf)
+__device__ __forceinline__ bool lr_rejected(const float *dL, const float *dR, int row0, int x, int W, float thr)
+{
+    const float d = dL[row0 + x];
+    if (d == INFINITY) return true;                                       // :90
+    const int cr = (int)((double)((float)x - d) + 0.5);                   // :96
+    if (cr >= 0 && cr < W) return fabsf(d - dR[row0 + cr]) > thr;         // :103
+    return true;                                                          // :128-131
+}
+
+__global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL, const float *__restrict__ dR,
+                                                    int H, int W, float thr, uint8_t *__restrict__ cls,
+                                                    int *counts)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= H * W) return;
+    const int i = p / W, j = p - i * W;
+    const int row0 = i * W;
+    const float d = dL[p];
+    uint8_t c = 0;
+    if (d == INFINITY) c = 2;
+    else {
+        const int cr = (int)((double)((float)j - d) + 0.5);
+        if (cr >= 0 && cr < W) {
+            const float dr = dR[row0 + cr];
+            if (fabsf(d - dr) > thr) {
+                const int crl = (int)((double)((float)cr + dr) + 0.5);    // :110
+                if (crl > 0 && crl < W) {
+                    float dl = dL[row0 + crl];
+                    if (crl < j && lr_rejected(dL, dR, row0, crl, W, thr)) dl = INFINITY;
+                    c = (dl > d) ? 1 : 2;                                 // :113-118
+                } else c = 2;
+            }
+        } else c = 2;
+    }
+    cls[p] = c;
+    if (counts && c) atomicAdd(&counts[c - 1], 1);
+}
+
+__global__ void __launch_bounds__(NT) k_lr_apply(float *__restrict__ dL, const uint8_t *__restrict__ cls, int n)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p < n && cls[p]) dL[p] = INFINITY;
+}
+
+__global__ void __launch_bounds__(NT) k_sad_crosscheck(const int32_t *__restrict__ dL, const int32_t *__restrict__ dR,
+                                                       int n, int32_t *__restrict__ out, uint8_t *__restrict__ cls)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n) return;
+    const int lv = dL[p];
+    const long idx = (long)p - lv;                                        // flat pointer arithmetic, Sad.h:204
+    const int rv = (idx >= 0 && idx < n) ? dR[idx] : 0;
+    const int diff = abs(lv - rv);
+    if (diff > 5) {                                                       // diffthreshold :192
+        cls[p] = (lv < rv) ? 1 : 2;
+        out[p] = INT32_MIN;                                               // int(inf) on x86
+    } else { cls[p] = 0; out[p] = lv; }
+}
+
+__global__ void __launch_bounds__(NT) k_asw_crosscheck(const float *__restrict__ dL, const float *__restrict__ dR,
+                                                       int n, uint8_t *__restrict__ out)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n) return;
+    const int lv = (int)dL[p];                                            // ASW.h:126
+    const long idx = (long)p - lv;
+    const float rv = (idx >= 0 && idx < n) ? dR[idx] : 0.0f;
+    const float diff = fabsf((float)lv - rv);
+    out[p] = (diff > 5.0f) ? 0 : (uint8_t)lv;
+}
+
+}  // namespace
+
+SMT_API int smt_lrcheck(float *dL, const float *dR, int H, int W, int gate, uint8_t *cls, int *counts,
+                        void *stream)
+{
+    if (!dL || !dR || !cls || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    hipStream_t st = smt_stream(stream);
+    const int n = H * W;
+    if (counts) SMT_HIP(hipMemsetAsync(counts, 0, 8, st));
+    hipLaunchKernelGGL(k_lr_classify, dim3((n + NT - 1) / NT), dim3(NT), 0, st, dL, dR, H, W, (float)gate, cls,
+                       counts);
+    hipLaunchKernelGGL(k_lr_apply, dim3((n + NT - 1) / NT), dim3(NT), 0, st, dL, cls, n);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_lrcheck_lists(const uint8_t *cls, int H, int W, int *occ, int *n_occ, int *mis, int *n_mis)
+{
+    if (!cls || !occ || !mis || !n_occ || !n_mis || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    int no = 0, nm = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const uint8_t c = cls[(size_t)i * W + j];
+            if (c == 1) { occ[2 * no] = i; occ[2 * no + 1] = j; no++; }       // emplace_back(i, j)
+            else if (c == 2) { mis[2 * nm] = i; mis[2 * nm + 1] = j; nm++; }
+        }
+    *n_occ = no; *n_mis = nm;
+    return SMT_OK;
+}
+
+SMT_API int smt_sad_crosscheck(const int32_t *dL, const int32_t *dR, int H, int W, int32_t *out, uint8_t *cls,
+                               void *stream)
+{
+    if (!dL || !dR || !out || !cls || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_sad_crosscheck, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), dL, dR, n, out,
+                       cls);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_asw_crosscheck(const float *dL, const float *dR, int H, int W, uint8_t *out, void *stream)
+{
+    if (!dL || !dR || !out || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_asw_crosscheck, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), dL, dR, n, out);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}

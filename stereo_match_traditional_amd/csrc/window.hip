@@ -1,0 +1,274 @@
+// Fixed-window matchers -- replace SAD/Sad.h (GetPointDepthLeft/Right, OptimalDisparity,
+// GetMinSadIndex), NCC/NCC.h (ComputeCost, WinTakeAll, NCC_algorithem) and ASW/ASW.h
+// (bilateralfiterWight, AdaptiveSupportWeight(Right), WinTakeAll).
+//
+// All three share one mapping: one wavefront per output pixel, the disparity axis strided
+// over the lanes (d = lane + 64*k), so that for every window tap the lanes read 64
+// consecutive bytes of the other image.  The per-pixel cost vectors are never written to
+// HBM unless the caller asks for them (the reference keeps them in a per-pixel
+// std::vector too).
+//
+// The reference's "copy the previous cost" branches (Sad.h:125-129,167-171; ASW.h:369-372,
+// 422-425) make cost[d] = cost[dmax] for d beyond the last in-range disparity dmax, i.e.
+// the hypothesis is evaluated at min(d, dmax).
+#include "smt_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int KMAX = 4;        // D <= 256
+
+// ---------------------------------------------------------------------------------- SAD
+// OptimalDisparity (Sad.h:40-85) over the wave-distributed vector sad[d], d = lane+64k.
+__device__ int sad_optimal(const float (&sad)[KMAX], int D, int lane)
+{
+    // min over d >= 1, first strict (:46-53), starting from 0xffff
+    float lm = 65535.0f; int ld = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int d = lane + 64 * k;
+        if (d >= 1 && d < D && lm > sad[k]) { lm = sad[k]; ld = d; }
+    }
+    const float minv = wave_min_f32(lm);
+    // first d >= 1 whose value equals the minimum (if any value beat 65535)
+    int cand = (lm == minv && ld != 0x7fffffff) ? ld : 0x7fffffff;
+    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+    const float best = (cand == 0x7fffffff) ? 65535.0f : (float)cand;
+    // second minimum: starts at sad[0]; every entry equal to minv is skipped (:55-64)
+    float ls = INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int d = lane + 64 * k;
+        if (d < D && !(minv == sad[k])) ls = fminf(ls, sad[k]);
+    }
+    const float s0 = __shfl(sad[0], 0, WAVE);
+    const float sec = fminf(s0, wave_min_f32(ls));
+    if ((double)(sec - minv) <= 0.01) return 0;                           // :66
+    if (best == 0.0f || best == (float)(D - 1)) return 0;                 // :71
+    return (int)best;                                                     // :84
+}
+
+// grid: one wave per ORIGINAL pixel (io, jo); Lp/Rp padded by w = winsize+1
+__global__ void __launch_bounds__(NT) k_sad(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                            int W, int D, int w, int view, int32_t *__restrict__ disp)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= H * W) return;
+    const int io = p / W, jo = p - io * W;
+    const int Wp = W + 2 * w, side = 2 * w + 1;
+    if (view == 1 && (io >= H - 1 || jo >= W - 1)) {                      // never written (:157,:160)
+        if (lane == 0) disp[p] = 0;
+        return;
+    }
+    const int dmax = (view == 0) ? jo : (W - 1 - jo);                     // last in-range disparity
+    float sad[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int d = lane + 64 * k;
+        sad[k] = 0.0f;
+        if (d < D) {
+            const int dd = d < dmax ? d : dmax;
+            // top-left corners of the two windows in padded coordinates
+            const uint8_t *a = (view == 0) ? Lp + (size_t)io * Wp + jo : Rp + (size_t)io * Wp + jo;
+            const uint8_t *b = (view == 0) ? Rp + (size_t)io * Wp + jo - dd : Lp + (size_t)io * Wp + jo + dd;
+            int s = 0;
+            for (int r = 0; r < side; r++)
+                for (int c = 0; c < side; c++) s += abs((int)a[r * Wp + c] - (int)b[r * Wp + c]);
+            sad[k] = (float)s;                                            // sadvalue :15-20
+        }
+    }
+    int out;
+    if (view == 0) out = sad_optimal(sad, D, lane);
+    else {                                                                // GetMinSadIndex :22-38
+        float lm = INFINITY; int ld = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            const int d = lane + 64 * k;
+            if (d < D && sad[k] < lm) { lm = sad[k]; ld = d; }
+        }
+        const float m = wave_min_f32(lm);
+        int cand = (lm == m) ? ld : 0x7fffffff;
+        for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+        out = cand;
+    }
+    if (lane == 0) disp[p] = out;
+}
+
+// ---------------------------------------------------------------------------------- NCC
+__device__ double ncc_cost(const uint8_t *a, const uint8_t *b, int W, int side)   // NCC.h:15-49
+{
+    double lm = 0, rm = 0, ls = 0, rs = 0, num = 0;
+    const int n = side * side;
+    for (int i = 0; i < side; i++)
+        for (int j = 0; j < side; j++) { lm += a[i * W + j]; rm += b[i * W + j]; }   // exact integer sums
+    lm /= n; rm /= n;
+    for (int i = 0; i < side; i++)
+        for (int j = 0; j < side; j++) {
+            const double x = a[i * W + j] - lm, y = b[i * W + j] - rm;
+            ls += x * x; rs += y * y; num += x * y;
+        }
+    return num / (sqrt(ls) * sqrt(rs));
+}
+
+__global__ void __launch_bounds__(NT) k_ncc(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int H, int W,
+                                            int D, int win, int32_t *__restrict__ disp, double *__restrict__ cost_out)
+{
+    __shared__ double s_cost[NT / 64][256];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= H * W) return;
+    const int i = p / W, j = p - i * W;
+    if (i < win || i >= H - win || j < win || j >= W - win) {             // border untouched (zeros)
+        if (lane == 0) disp[p] = 0;
+        return;
+    }
+    const int side = 2 * win + 1;
+    for (int d = lane; d < D; d += 64) {
+        double c;
+        if (j - win - d >= 0)
+            c = ncc_cost(L + (size_t)(i - win) * W + (j - win), R + (size_t)(i - win) * W + (j - win - d), W, side);
+        else c = 255.0;                                                   // `invalid` 0xff, NCC.h:88
+        s_cost[wv][d] = c;
+        if (cost_out) cost_out[(size_t)p * D + d] = c;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {                                                      // WinTakeAll :53-67 (sequential, float-narrowed)
+        int best = 0;
+        float m = (float)s_cost[wv][0];
+        for (int d = 1; d < D; d++)
+            if ((double)m < s_cost[wv][d]) { best = d; m = (float)s_cost[wv][d]; }
+        disp[p] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------- ASW
+__global__ void __launch_bounds__(NT) k_asw(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                            int W, int D, int wins, const double *__restrict__ space,
+                                            const double *__restrict__ color, int T, int view,
+                                            float *__restrict__ disp, float *__restrict__ cost_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int side = 2 * wins + 1;
+    double *s_color = (double *)smem;                 // 256
+    double *s_space = s_color + 256;                  // side*side
+    for (int e = threadIdx.x; e < 256; e += NT) s_color[e] = color[e];
+    for (int e = threadIdx.x; e < side * side; e += NT) s_space[e] = space[e];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= H * W) return;
+    const int io = p / W, jo = p - io * W;
+    const int Wp = W + 2 * wins;
+    // anchor window: left image for view 0, right image for view 1 (ASW.h:342 / :395)
+    const uint8_t *A = (view == 0 ? Lp : Rp) + (size_t)io * Wp + jo;
+    const uint8_t *B = (view == 0 ? Rp : Lp) + (size_t)io * Wp + jo;
+    // last in-range disparity: left j-wins-d >= 0 (:348); right j+wins+d+1 < Wp-wins (:401)
+    const int dmax = (view == 0) ? jo : (W - wins - 2 - jo);
+    const int ca = A[wins * Wp + wins];
+    float cv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int d = lane + 64 * k;
+        cv[k] = 0.0f;
+        if (d < D && dmax >= 0) {
+            const int dd = d < dmax ? d : dmax;
+            const uint8_t *b = (view == 0) ? B - dd : B + dd;
+            const int cb = b[wins * Wp + wins];
+            double sw = 0, sv = 0;
+            for (int r = 0; r < side; r++)
+                for (int c = 0; c < side; c++) {
+                    const int pa = A[r * Wp + c], pb = b[r * Wp + c];
+                    const double sp = s_space[r * side + c];
+                    const double m0 = s_color[abs(pa - ca)] * sp;         // Mask0 :229-230
+                    const double m1 = s_color[abs(pb - cb)] * sp;         // Mask1 :244-245
+                    const double m2 = m0 * m1;                            // :248
+                    int e = abs(pa - pb);
+                    e = e > T ? T : e;                                    // :358-366
+                    sw += m2;                                             // :252
+                    sv += m2 * (double)e;                                 // :253-255
+                }
+            cv[k] = (float)(sv / sw);
+        }
+    }
+    // WinTakeAll: first strict minimum (:193-208).  dmax < 0 (right view, last columns): the
+    // reference chains every cost to an out-of-bounds read -> all equal -> 0.
+    float lm = INFINITY; int ld = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        const int d = lane + 64 * k;
+        if (d < D && lm > cv[k]) { lm = cv[k]; ld = d; }
+    }
+    const float m = wave_min_f32(lm);
+    int cand = (lm == m) ? ld : 0x7fffffff;
+    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+    if (lane == 0) disp[p] = (dmax < 0) ? 0.0f : (float)cand;
+    if (cost_out) {
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) {
+            const int d = lane + 64 * k;
+            if (d < D) cost_out[(size_t)p * D + d] = (dmax < 0) ? NAN : cv[k];
+        }
+    }
+}
+
+}  // namespace
+
+SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winsize, int view,
+                    int32_t *disp, void *stream)
+{
+    if (!Lp || !Rp || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256 || winsize < 0 ||
+        (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT))
+        return SMT_ERR_ARG;
+    const int N = H * W;
+    hipLaunchKernelGGL(k_sad, dim3((N + 3) / 4), dim3(NT), 0, smt_stream(stream), Lp, Rp, H, W, D, winsize + 1,
+                       view == SMT_VIEW_LEFT ? 0 : 1, disp);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int winSize, int32_t *disp,
+                    double *cost, void *stream)
+{
+    if (!L || !R || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256 || winSize < 0) return SMT_ERR_ARG;
+    const int N = H * W;
+    hipLaunchKernelGGL(k_ncc, dim3((N + 3) / 4), dim3(NT), 0, smt_stream(stream), L, R, H, W, D, winSize, disp, cost);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_asw_masks(int winSize, double sigma_s, double sigma_c, double *space, double *color)
+{
+    if (!space || !color || winSize < 0) return SMT_ERR_ARG;
+    const int side = 2 * winSize + 3, c = (side - 1) / 2;
+    for (int i = 0; i < side; i++) {
+        const double y = (double)((i - c) * (i - c));                     // pow(i - center_h, 2), ASW.h:26
+        for (int j = 0; j < side; j++) {
+            const double x = (double)((j - c) * (j - c));
+            space[i * side + j] = exp(-(x + y) / (2 * sigma_s * sigma_s)); // :30
+        }
+    }
+    for (int i = 0; i < 256; i++) color[i] = exp(-(i * i) / (2 * sigma_c * sigma_c)); // :44
+    return SMT_OK;
+}
+
+SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSize, const double *space,
+                    const double *color, int T, int view, float *disp, float *cost, void *stream)
+{
+    if (!Lp || !Rp || !space || !color || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256 || winSize < 0 ||
+        (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT))
+        return SMT_ERR_ARG;
+    const int wins = winSize + 1, side = 2 * wins + 1;
+    const size_t shm = (size_t)(256 + side * side) * 8;
+    if (shm > 150 * 1024) return SMT_ERR_ARG;
+    const int N = H * W;
+    hipLaunchKernelGGL(k_asw, dim3((N + 3) / 4), dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, wins, space,
+                       color, T, view == SMT_VIEW_LEFT ? 0 : 1, disp, cost);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}

@@ -71,3 +71,35 @@ def test_lib_exports_every_declared_symbol():
     missing = [n for n in sorted(set(names)) if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.smt_version() == 100
+
+
+def test_oracle_vs_golden_fixtures(O):
+    """Oracle vs the committed fixtures (CrossAggregator outputs of the reference build;
+    expf tables of the build container's libm)."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    n = 0
+    for f in sorted(os.listdir(gold)):
+        if f.startswith("crossagg_") and f.endswith(".npz"):
+            z = np.load(os.path.join(gold, f))
+            L1, L2, t1, t2, iters = [int(v) for v in z["params"]]
+            a, c = O.crossagg(z["bgr"], z["cost_init"], L1, L2, t1, t2, iters)
+            assert np.array_equal(a, z["arms"])
+            assert np.array_equal(c.view(np.uint32), z["cost_out"].view(np.uint32))
+            n += 1
+    assert n >= 3
+    z = np.load(os.path.join(gold, "adcensus_luts_sc10_ss30.npz"))
+    a, c = O.fuse_luts(10.0, 30.0)
+    assert np.array_equal(a.view(np.uint32), z["lutA"].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), z["lutC"].view(np.uint32))
+
+
+def test_lrcheck_order_dependence_is_modelled(O):
+    """A crafted row where the in-place write changes a later classification (:112 after :125)."""
+    W = 12
+    dL = np.zeros((1, W), np.float32)
+    dR = np.zeros((1, W), np.float32)
+    dL[0, 2] = 9       # cr = -7 -> out of range -> inf (mismatch)
+    dL[0, 6] = 3       # cr = 3, dR[3] = -1... set so that crl = 2 (< 6) which is now inf
+    dR[0, 3] = -1
+    ref, cls, no, nm = O.lrcheck(dL, dR, 0)
+    assert cls[0, 6] == 1 and np.isinf(ref[0, 2])    # reads inf at crl=2 -> occlusion

@@ -1,0 +1,238 @@
+"""CrossArm arms + aggregation, ScanlineOptimizer, LeftRightConsistency, CBLSM variants:
+HIP path (through the C ABI) vs the CPU oracle, bit-exact.  Oracle = loop-for-loop
+restatement of AD-CensusV1/{CrossArm.cpp,ScanlineOptimizer.h,PostProcessing.h} and
+CBLSM/CBLSM.h ("parity unpinned", see oracle/smt_oracle.c)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def smooth_img(H, W, seed, step=3):
+    """piecewise-smooth image with long flat runs so arms pass 17 and the sticky tau flips"""
+    rng = np.random.default_rng(seed)
+    base = (np.add.outer(np.arange(H) // 9, np.arange(W) // 23) * 17) % 200 + 20
+    return (base + rng.integers(0, step, (H, W))).astype(np.uint8)
+
+
+ARM_CASES = [
+    # H, W, kind, seed
+    (72, 160, "synth", 3),
+    (72, 160, "noise", 4),      # never flips tau
+    (64, 150, "smooth", 5),     # flips in the first direction
+    (40, 200, "smooth", 6),
+    (30, 64, "flat", 0),        # constant image: every arm saturates
+]
+
+
+def _img(H, W, kind, seed, O):
+    if kind == "synth":
+        return O.synth_pair(H, W, 32, seed)[0]
+    if kind == "noise":
+        return O.synth_pair(H, W, 32, seed, True)[0]
+    if kind == "smooth":
+        return smooth_img(H, W, seed)
+    return np.full((H, W), 77, np.uint8)
+
+
+@pytest.mark.parametrize("H,W,kind,seed", ARM_CASES)
+@pytest.mark.parametrize("style", ["adcensus", "cblsm"])
+def test_arms(smt, O, H, W, kind, seed, style):
+    img = _img(H, W, kind, seed, O)
+    ca = smt.CrossArmAggregation()
+    if style == "adcensus":
+        ref = O.arms_all(img, 30, 6, 17, 34, chain=True, right_row_bug=True)
+        ca.Initialize(H, W, 30, 16, DEV)
+    else:
+        ref = O.arms_all(img, 25, 6, 17, 34, chain=False, right_row_bug=False)
+        ca.Initialize(H, W, 25, 16, DEV, style="cblsm")
+    ca.ComputeArmLengths(T(img))
+    got = [a.cpu().numpy() for a in ca.arm_maps()]
+    for name, g, r in zip("LRTB", got, ref):
+        assert np.array_equal(g, r), f"arm {name} differs ({(g != r).sum()} px)"
+    ca.close()
+
+
+def test_arms_flip_inside_later_direction(smt, O):
+    """tau must survive the left pass and flip in the top pass: columns are flat, rows are not."""
+    H, W = 60, 140
+    rng = np.random.default_rng(1)
+    img = np.tile((rng.integers(0, 2, W) * 120 + 40).astype(np.uint8), (H, 1))
+    ref = O.arms_all(img)
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, 8, DEV)
+    ca.ComputeArmLengths(T(img))
+    for g, r in zip(ca.arm_maps(), ref):
+        assert np.array_equal(g.cpu().numpy(), r)
+    ca.close()
+
+
+def test_arms_three_channel(smt, O):
+    H, W = 50, 120
+    g = smooth_img(H, W, 9)
+    img = O.synth_bgr(g, 4)
+    ref = O.arms_all(img)
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, 8, DEV)
+    ca.ComputeArmLengths(T(img))
+    for a, r in zip(ca.arm_maps(), ref):
+        assert np.array_equal(a.cpu().numpy(), r)
+    ca.close()
+
+
+AGG_CASES = [(72, 160, 16, "synth", 3), (64, 150, 64, "smooth", 5), (72, 160, 100, "noise", 4),
+             (48, 180, 192, "synth", 8)]
+
+
+@pytest.mark.parametrize("H,W,D,kind,seed", AGG_CASES)
+@pytest.mark.parametrize("order", [0, 1])
+def test_aggregation(smt, O, H, W, D, kind, seed, order):
+    img = _img(H, W, kind, seed, O)
+    vol = np.random.default_rng(seed).random((H, W, D), dtype=np.float32) * 2
+    style = "adcensus" if order == 0 else "cblsm"
+    if order == 0:
+        arms = O.arms_all(img)
+    else:
+        arms = O.arms_all(img, 25, 6, 17, 34, chain=False, right_row_bug=False)
+    ref, oob = O.aggregate_rect(vol, arms, order)
+    assert oob == 0, "test size must not trigger the reference's out-of-plane reads"
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30 if order == 0 else 25, D, DEV, style=style)
+    ca.ComputeArmLengths(T(img))
+    out = torch.empty((H, W, D), device=DEV)
+    disp = torch.empty((H, W), device=DEV)
+    (ca.AggregationVertical if order == 0 else ca.costAggregationV5)(T(vol), out, disp)
+    ca.status()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    assert np.array_equal(disp.cpu().numpy(), O.wta(ref))
+    ca.close()
+
+
+def test_aggregation_flags_reference_ub(smt, O):
+    """Small image + stride bug -> rectangles leave the plane: reference UB, status says so."""
+    from stereo_match_traditional_amd import SmtError
+    H, W, D = 24, 40, 8
+    img = np.full((H, W), 50, np.uint8)
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.ComputeArmLengths(T(img))
+    out = torch.empty((H, W, D), device=DEV)
+    ca.AggregationVertical(torch.rand((H, W, D), device=DEV), out)
+    with pytest.raises(SmtError):
+        ca.status()
+    ca.close()
+
+
+def test_cblsm_ad(smt, O):
+    H, W, D = 20, 70, 60
+    L, R = O.synth_pair(H, W, D, 5)
+    for view, v in ((smt.VIEW_LEFT, 0), (smt.VIEW_RIGHT, 1)):
+        got = smt.cblsm_ComputeAD(T(L), T(R), D, view).cpu().numpy()
+        assert np.array_equal(bits(got), bits(O.cblsm_ad(L, R, D, v)))
+
+
+SCAN_CASES = [(20, 40, 16, 3), (12, 70, 64, 4), (9, 33, 100, 5), (10, 50, 192, 6), (7, 21, 256, 7), (3, 5, 8, 8)]
+
+
+@pytest.mark.parametrize("H,W,D,seed", SCAN_CASES)
+def test_scanline_passes_and_sum(smt, O, H, W, D, seed):
+    rng = np.random.default_rng(seed)
+    cost = rng.random((H, W, D), dtype=np.float32) * 2
+    gray = rng.integers(0, 256, (H, W)).astype(np.float32)
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
+    for which in ("left", "right", "up", "down"):
+        got = so.ScanPass(T(cost), T(gray), which).cpu().numpy()
+        ref = O.scan_pass(cost, gray, 10, 150, which)
+        assert np.array_equal(bits(got), bits(ref)), which
+    disp = torch.empty((H, W), device=DEV)
+    out = so.ScanLine(T(cost), T(gray), disp=disp).cpu().numpy()
+    ref = O.scanline(cost, gray, 10, 150)
+    assert np.array_equal(bits(out), bits(ref))
+    assert np.array_equal(disp.cpu().numpy(), O.wta(ref))
+    d2 = torch.empty((H, W), device=DEV)
+    so.WTA(d2)
+    assert np.array_equal(d2.cpu().numpy(), O.wta(ref))
+    so.close()
+
+
+def test_scanline_on_real_costs(smt, O):
+    """ScanLine fed with AD-Census costs and image-derived p2 (smooth gray -> large p2)."""
+    H, W, D = 16, 96, 64
+    L, R = O.synth_pair(H, W, D, 11)
+    cost = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
+    gray = L.astype(np.float32)
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
+    out = so.ScanLine(T(cost), T(gray)).cpu().numpy()
+    assert np.array_equal(bits(out), bits(O.scanline(cost, gray, 10, 150)))
+    so.close()
+
+
+@pytest.mark.parametrize("H,W,seed,gate", [(20, 60, 1, 2), (9, 200, 2, 1), (30, 31, 3, 5)])
+def test_lrcheck(smt, O, H, W, seed, gate):
+    rng = np.random.default_rng(seed)
+    dL = rng.integers(0, 24, (H, W)).astype(np.float32)
+    dR = rng.integers(0, 24, (H, W)).astype(np.float32)
+    dL[rng.random((H, W)) < 0.05] = np.inf          # already-invalid inputs (:90-93)
+    ref, cls, no, nm = O.lrcheck(dL, dR, gate)
+    t = T(dL.copy())
+    gcls, gno, gnm, occ, mis = smt.LeftRightConsistency(W, H, gate, t, T(dR), want_lists=True)
+    assert np.array_equal(gcls.cpu().numpy(), cls)
+    assert (gno, gnm) == (no, nm)
+    assert np.array_equal(bits(t.cpu().numpy()), bits(ref))
+    assert np.array_equal(occ, np.argwhere(cls == 1)) and np.array_equal(mis, np.argwhere(cls == 2))
+
+
+def test_lrcheck_on_pipeline_maps(smt, O):
+    H, W, D = 24, 120, 32
+    L, R = O.synth_pair(H, W, D, 6)
+    dl = O.wta(O.adcensus_view(L, R, D, 10.0, 30.0, 0))
+    dr = O.wta(O.adcensus_view(L, R, D, 10.0, 30.0, 1))
+    ref, cls, no, nm = O.lrcheck(dl, dr, 2)
+    t = T(dl.copy())
+    gcls, gno, gnm = smt.LeftRightConsistency(W, H, 2, t, T(dr))
+    assert np.array_equal(gcls.cpu().numpy(), cls) and (gno, gnm) == (no, nm)
+    assert np.array_equal(bits(t.cpu().numpy()), bits(ref))
+
+
+def test_full_pipeline_config3_shape(smt, O):
+    """main.cpp:57-92 order: AD-Census (L,R) -> arms+AggregationVertical (L on leftGray, R on
+    rightGray) -> ScanLine on the left aggregated volume -> WTA -> LeftRightConsistency."""
+    H, W, D = 72, 160, 64
+    L, R = O.synth_pair(H, W, D, 3)
+    # oracle
+    cl = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
+    cr = O.adcensus_view(L, R, D, 10.0, 30.0, 1)
+    al, oob1 = O.aggregate_rect(cl, O.arms_all(L), 0)
+    ar, oob2 = O.aggregate_rect(cr, O.arms_all(R), 0)
+    assert oob1 == 0 and oob2 == 0
+    so_ref = O.scanline(al, L.astype(np.float32), 10, 150)
+    dl_ref, dr_ref = O.wta(so_ref), O.wta(ar)
+    lr_ref, cls_ref, no, nm = O.lrcheck(dl_ref, dr_ref, 2)
+    # engine
+    Lf, Rf = T(L.astype(np.float32)), T(R.astype(np.float32))
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+    adc.ComputeBoth()
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    aggL = torch.empty((H, W, D), device=DEV)
+    aggR = torch.empty((H, W, D), device=DEV)
+    dR = torch.empty((H, W), device=DEV)
+    ca.ComputeArmLengths(T(L))
+    ca.AggregationVertical(adc.GetPtrLeft(), aggL)
+    ca.Initialize(H, W, 30, D, DEV)
+    ca.ComputeArmLengths(T(R))
+    ca.AggregationVertical(adc.GetPtrRight(), aggR, dR)
+    ca.status()
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
+    dL = torch.empty((H, W), device=DEV)
+    out = so.ScanLine(aggL, Lf, disp=dL)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(so_ref))
+    assert np.array_equal(dR.cpu().numpy(), dr_ref)
+    cls, gno, gnm = smt.LeftRightConsistency(W, H, 2, dL, dR)
+    assert np.array_equal(cls.cpu().numpy(), cls_ref) and (gno, gnm) == (no, nm)
+    assert np.array_equal(bits(dL.cpu().numpy()), bits(lr_ref))
