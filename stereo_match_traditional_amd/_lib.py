@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmt_hip.so")
+LIB_PATH = os.environ.get("SMT_HIP_LIB") or os.path.join(_HERE, "lib", "libsmt_hip.so")  # override: A/B kernel builds
 
 SMT_OK = 0
 SMT_ERR_DOMAIN = -4

@@ -63,15 +63,19 @@ __global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img
     const int dir = blockIdx.y;
     const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
     const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= c.H * colR) return;
-    const int i = idx / colR, j = idx - i * colR;
-    bool ok = true;
+    bool ok = idx < c.H * colR;
+    const int i = ok ? idx / colR : 0, j = ok ? idx - i * colR : 0;
     for (int k = 1; k <= c.sec && ok; k++) {
         int ni, nj;
         ok = arm_nb(dir, i, j, k, c.H, colR, ni, nj);
         if (ok) ok = pix_diff(img, c.ch, i * c.W + j, ni * c.W + nj) <= c.tau;
     }
-    if (ok) atomicMin(&flip[dir], idx);
+    // lanes are in index order: the wave's candidate is its first set lane
+    const unsigned long long b = __ballot(ok);
+    if (b && (threadIdx.x & 63) == 0) {
+        const int cand = idx + __builtin_ctzll(b);
+        if (cand < *(volatile int *)&flip[dir]) atomicMin(&flip[dir], cand);
+    }
 }
 
 __global__ void __launch_bounds__(NT) k_arms(const uint8_t *__restrict__ img, ArmCfg c,

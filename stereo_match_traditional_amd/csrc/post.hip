@@ -29,12 +29,13 @@ __global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL
                                                     int *counts)
 {
     const int p = blockIdx.x * NT + threadIdx.x;
-    if (p >= H * W) return;
-    const int i = p / W, j = p - i * W;
+    const bool live = p < H * W;
+    const int i = live ? p / W : 0, j = live ? p - i * W : 0;
     const int row0 = i * W;
-    const float d = dL[p];
+    const float d = live ? dL[p] : 0.0f;
     uint8_t c = 0;
-    if (d == INFINITY) c = 2;
+    if (!live) c = 0;
+    else if (d == INFINITY) c = 2;
     else {
         const int cr = (int)((double)((float)j - d) + 0.5);
         if (cr >= 0 && cr < W) {
@@ -49,8 +50,14 @@ __global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL
             }
         } else c = 2;
     }
-    cls[p] = c;
-    if (counts && c) atomicAdd(&counts[c - 1], 1);
+    if (live) cls[p] = c;
+    if (counts) {                                          // one atomic per wave and class
+        const int n1 = __popcll(__ballot(c == 1)), n2 = __popcll(__ballot(c == 2));
+        if ((threadIdx.x & 63) == 0) {
+            if (n1) atomicAdd(&counts[0], n1);
+            if (n2) atomicAdd(&counts[1], n2);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(NT) k_lr_apply(float *__restrict__ dL, const uint8_t *__restrict__ cls, int n)

@@ -13,15 +13,22 @@
 // (:221, :250) and never update grayLast (:210).
 //
 // The reference stores four path volumes and then adds them ((left+right)+up)+down
-// (:124).  Here pass 0 writes the output volume and passes 1..3 accumulate into it in
-// that same association order; the last pass can fuse ScanlineOptimizer::WTA (:40-64).
+// (:124).  Here the left and right passes run CONCURRENTLY in one launch (2H scanlines in
+// flight instead of H) into the output volume and one scratch volume; the up pass then
+// writes (left + right) + up and the down pass adds itself and can fuse
+// ScanlineOptimizer::WTA (:40-64).  Same association order, 44 bytes of HBM traffic per
+// hypothesis in total (8 + 8 + 16 + 12).
 #include "smt_common.h"
 #include <new>
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int PF = 4;             // prefetch depth (scan steps)
+#ifndef SMT_SCAN_PF
+#define SMT_SCAN_PF 8
+#endif
+constexpr int PF = SMT_SCAN_PF;            // prefetch depth (scan steps): loads are issued PF steps ahead so the
+                                  // in-order vmcnt wait never lands behind the step's own stores
 constexpr float PAD = 65535.0f;   // 0xffff as float (:151, :162, :169)
 
 template <int CTRL>
@@ -51,137 +58,198 @@ struct ScanArgs {
     const float *cost;   // [H][W][D]
     const float *gray;   // [H][W]
     float *out;          // [H][W][D]
+    const float *add2;   // MODE 3: second addend volume (right path), else unused
+    float *out_b;        // k_scan_lr: destination of the right->left pass
     float *disp;         // fused WTA of the accumulated volume (last pass) or null
     int H, W, D;
     float p1, p2;
     int accumulate;      // out = out + path instead of out = path
 };
 
-// PASS: 0 left->right, 1 right->left, 2 top->bottom, 3 bottom->top
-template <int C, int PASS>
-__global__ void __launch_bounds__(NT) k_scan(ScanArgs a)
+template <int C> struct vecf;
+template <> struct vecf<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
+template <> struct vecf<3> { float v[3]; };
+template <> struct __attribute__((aligned(16))) vecf<4> { float v[4]; };
+
+// row of C consecutive floats per lane; FULL (D == 64*C): one unpredicated vector access
+template <int C, bool FULL>
+__device__ __forceinline__ void ld_row(const float *p, int dl, int D, float fill, float (&dst)[C])
 {
+    if (FULL) {
+        const vecf<C> x = *reinterpret_cast<const vecf<C> *>(p);
+#pragma unroll
+        for (int k = 0; k < C; k++) dst[k] = x.v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; k++) dst[k] = (dl + k < D) ? p[k] : fill;
+    }
+}
+template <int C, bool FULL>
+__device__ __forceinline__ void st_row(float *p, int dl, int D, const float (&src)[C])
+{
+    if (FULL) {
+        vecf<C> x;
+#pragma unroll
+        for (int k = 0; k < C; k++) x.v[k] = src[k];
+        *reinterpret_cast<vecf<C> *>(p) = x;
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+            if (dl + k < D) p[k] = src[k];
+    }
+}
+
+// PASS: 0 left->right, 1 right->left, 2 top->bottom, 3 bottom->top
+// MODE: 0 out = path ; 1 out = out + path ; 2 out = out + path and fused WTA of the sum ;
+//       3 out = (out + add2) + path
+template <int C, int PASS, int MODE, bool FULL>
+__device__ __forceinline__ void scan_body(const ScanArgs &a, float *out, int line)
+{
+    constexpr bool ACC = (MODE >= 1);
+    constexpr bool ACC2 = (MODE == 3);
+    constexpr bool WTA = (MODE == 2);
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int line = blockIdx.x * (NT / 64) + wv;
     constexpr bool HORIZ = (PASS < 2);
     const int H = a.H, W = a.W, D = a.D;
     const int nlines = HORIZ ? H : W;
     if (line >= nlines) return;
     const int nsteps = HORIZ ? W : H;                 // pixels on the line
-    const int dirn = (PASS == 0 || PASS == 2) ? 1 : -1;
+    constexpr int dirn = (PASS == 0 || PASS == 2) ? 1 : -1;
 
     // pixel index (flat, in pixels) of step s:  start + s*pstride
-    long start;
-    long pstride;
+    long start, pstride;
     if (HORIZ) { start = (long)line * W + (dirn > 0 ? 0 : W - 1); pstride = dirn; }
     else       { start = (long)(dirn > 0 ? 0 : H - 1) * W + line; pstride = (long)dirn * W; }
     // gray pointer: horizontal passes follow the pixel; vertical passes step by ONE element (:221,:250)
-    const long gstart = start;
-    const long gstride = dirn;
-
+    const float *gp = a.gray + start;
     const int dl = lane * C;
-    bool act[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) act[k] = (dl + k < D);
+    const float *cp = a.cost + dl;
+    float *op = out + dl;
+    const float *qp = a.add2 + dl;
+    const float p1 = a.p1;
 
-    auto load_cost = [&](long pix, float (&dst)[C]) {
-        const float *src = a.cost + pix * D + dl;
+    auto wta_store = [&](const float (&res)[C], long pix) {
+        float best = INFINITY; int bk = 0;
 #pragma unroll
-        for (int k = 0; k < C; k++) dst[k] = act[k] ? src[k] : PAD;
+        for (int k = 0; k < C; k++)
+            if ((FULL || dl + k < D) && (k == 0 || best > res[k])) { best = res[k]; bk = k; }
+        if (!FULL && dl >= D) best = INFINITY;
+        const int wd = wave_argmin_first(best, dl + bk);
+        if (lane == 0) a.disp[pix] = (float)wd;
     };
 
     float last[C];
     // first pixel: path = cost (:153-155)
-    load_cost(start, last);
+    ld_row<C, FULL>(cp + start * D, dl, D, PAD, last);
     {
-        float *dst = a.out + start * D + dl;
         float res[C];
+        if (ACC) {
+            float o[C];
+            ld_row<C, FULL>(op + start * D, dl, D, 0.0f, o);
+            if (ACC2) {
+                float q[C];
+                ld_row<C, FULL>(qp + start * D, dl, D, 0.0f, q);
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-            res[k] = last[k];
-            if (a.accumulate && act[k]) res[k] = dst[k] + last[k];
-            if (act[k]) dst[k] = res[k];
-        }
-        if (a.disp) {
-            float best = INFINITY; int bk = 0;
+                for (int k = 0; k < C; k++) o[k] = o[k] + q[k];
+            }
 #pragma unroll
-            for (int k = 0; k < C; k++)
-                if (act[k] && (k == 0 || best > res[k])) { best = res[k]; bk = k; }
-            if (dl >= D) best = INFINITY;
-            const int wd = wave_argmin_first(best, dl + bk);
-            if (lane == 0) a.disp[start] = (float)wd;
+            for (int k = 0; k < C; k++) res[k] = o[k] + last[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++) res[k] = last[k];
         }
+        st_row<C, FULL>(op + start * D, dl, D, res);
+        if (WTA) wta_store(res, start);
     }
     // minLastPath = min over the padded vector (:162-166); pads are 65535
     float lm = PAD;
 #pragma unroll
     for (int k = 0; k < C; k++) lm = ref_min(last[k], lm);
     float minLast = wave_min_f32_dpp(lm);
+    float lastgray = gp[0];
 
-    float lastgray = a.gray[gstart];
-
-    // prefetch ring
+    // prefetch rings: cost row, guidance gray and (when accumulating) the running sum.
+    // Loads run PF steps ahead; indices past the end are clamped (harmless re-read) so the
+    // steady-state step has no branch and its vmcnt wait is an exact count.
     float cbuf[PF][C];
+    float obuf[ACC ? PF : 1][C];
+    float qbuf[ACC2 ? PF : 1][C];
+    float gbuf[PF];
+    const int slast = nsteps - 1;
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+        const int sp = min(1 + u, slast);
+        gbuf[u] = gp[(long)sp * dirn];
+        ld_row<C, FULL>(cp + (start + (long)sp * pstride) * D, dl, D, PAD, cbuf[u]);
+        if (ACC) ld_row<C, FULL>(op + (start + (long)sp * pstride) * D, dl, D, 0.0f, obuf[ACC ? u : 0]);
+        if (ACC2) ld_row<C, FULL>(qp + (start + (long)sp * pstride) * D, dl, D, 0.0f, qbuf[ACC2 ? u : 0]);
+    }
+
+#define SMT_SCAN_STEP(u, s)                                                                     \
+    {                                                                                           \
+        const long pix = start + (long)(s) * pstride;                                           \
+        const float g = gbuf[u];                                                                \
+        const float p2 = ref_max(p1, a.p2 / (fabsf(g - lastgray) + 1.0f)); /* :171 / :232 */    \
+        if (HORIZ) lastgray = g;                                           /* :172 only */      \
+        const float up_in = dpp_shift_f32<0x138>(last[C - 1], PAD); /* wave_shr:1 */            \
+        const float dn_in = dpp_shift_f32<0x130>(last[0], PAD);     /* wave_shl:1 */            \
+        const float l4 = minLast + p2;                                                          \
+        float cur[C];                                                                           \
+        float cm = PAD;                                                                         \
+        _Pragma("unroll") for (int k = 0; k < C; k++) {                                         \
+            const float lprev = (k == 0) ? up_in : last[k == 0 ? 0 : k - 1];                    \
+            float lnext = (k == C - 1) ? dn_in : last[k == C - 1 ? k : k + 1];                  \
+            if (dl + k + 1 >= D) lnext = PAD; /* entries past D-1 are the pad */                \
+            const float l1 = last[k];                                                           \
+            const float l2 = (HORIZ ? lprev : last[k]) + p1; /* :177 vs :238 (sic) */           \
+            const float l3 = lnext + p1;                                                        \
+            const float m = ref_min(ref_min(l1, l2), ref_min(l3, l4));                          \
+            const float cs = cbuf[u][k] + m - minLast; /* :180 */                               \
+            cur[k] = cs;                                                                        \
+            if (FULL || dl + k < D) cm = ref_min(cm, cs);                                       \
+        }                                                                                       \
+        float res[C];                                                                           \
+        _Pragma("unroll") for (int k = 0; k < C; k++)                                           \
+            res[k] = ACC2 ? (obuf[ACC ? u : 0][k] + qbuf[ACC2 ? u : 0][k]) + cur[k]             \
+                          : (ACC ? obuf[ACC ? u : 0][k] + cur[k] : cur[k]);                     \
+        st_row<C, FULL>(op + pix * D, dl, D, res);                                              \
+        if (WTA) wta_store(res, pix);                                                           \
+        minLast = wave_min_f32_dpp(cm);                                                         \
+        _Pragma("unroll") for (int k = 0; k < C; k++) last[k] = (FULL || dl + k < D) ? cur[k] : PAD; \
+        const int sp = min((s) + PF, slast);                                                    \
+        gbuf[u] = gp[(long)sp * dirn];                                                          \
+        ld_row<C, FULL>(cp + (start + (long)sp * pstride) * D, dl, D, PAD, cbuf[u]);            \
+        if (ACC) ld_row<C, FULL>(op + (start + (long)sp * pstride) * D, dl, D, 0.0f, obuf[ACC ? u : 0]); \
+        if (ACC2) ld_row<C, FULL>(qp + (start + (long)sp * pstride) * D, dl, D, 0.0f, qbuf[ACC2 ? u : 0]); \
+    }
+
+    int s0 = 1;
+    for (; s0 + PF <= nsteps; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) SMT_SCAN_STEP(u, s0 + u)
+    }
 #pragma unroll
     for (int u = 0; u < PF; u++)
-        if (1 + u < nsteps) load_cost(start + (long)(1 + u) * pstride, cbuf[u]);
+        if (s0 + u < nsteps) SMT_SCAN_STEP(u, s0 + u)
+#undef SMT_SCAN_STEP
+}
 
-    for (int s0 = 1; s0 < nsteps; s0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int s = s0 + u;
-            if (s < nsteps) {
-                const long pix = start + (long)s * pstride;
-                const float g = a.gray[gstart + (long)s * gstride];
-                const float p2 = ref_max(a.p1, a.p2 / (fabsf(g - lastgray) + 1.0f));   // :171 / :232
-                if (HORIZ) lastgray = g;                                                 // :172 (not in up/down)
-                // neighbours of the previous path vector
-                const float up_in = dpp_shift_f32<0x138>(last[C - 1], PAD);   // wave_shr:1 -> from lane-1
-                const float dn_in = dpp_shift_f32<0x130>(last[0], PAD);       // wave_shl:1 -> from lane+1
-                const float l4 = minLast + p2;
-                float cur[C];
-                float cm = PAD;
-#pragma unroll
-                for (int k = 0; k < C; k++) {
-                    const float lprev = (k == 0) ? up_in : last[k - 1];
-                    float lnext = (k == C - 1) ? dn_in : last[k + 1];
-                    // entries past D-1 are the pad value, whichever lane holds them
-                    if (dl + k + 1 >= D) lnext = PAD;
-                    const float l1 = last[k];
-                    const float l2 = (HORIZ ? lprev : last[k]) + a.p1;        // :177 vs :238 (sic)
-                    const float l3 = lnext + a.p1;
-                    const float m = ref_min(ref_min(l1, l2), ref_min(l3, l4));
-                    const float cs = cbuf[u][k] + m - minLast;               // :180
-                    cur[k] = cs;
-                    if (act[k]) cm = ref_min(cm, cs);
-                }
-                // write (or accumulate) the path value
-                float *dst = a.out + pix * D + dl;
-                float res[C];
-#pragma unroll
-                for (int k = 0; k < C; k++) {
-                    res[k] = cur[k];
-                    if (a.accumulate && act[k]) res[k] = dst[k] + cur[k];
-                    if (act[k]) dst[k] = res[k];
-                }
-                if (a.disp) {
-                    float best = INFINITY; int bk = 0;
-#pragma unroll
-                    for (int k = 0; k < C; k++)
-                        if (act[k] && (k == 0 || best > res[k])) { best = res[k]; bk = k; }
-                    if (dl >= D) best = INFINITY;
-                    const int wd = wave_argmin_first(best, dl + bk);
-                    if (lane == 0) a.disp[pix] = (float)wd;
-                }
-                minLast = wave_min_f32_dpp(cm);
-#pragma unroll
-                for (int k = 0; k < C; k++) last[k] = act[k] ? cur[k] : PAD;
-                // refill this ring slot
-                if (s + PF < nsteps) load_cost(start + (long)(s + PF) * pstride, cbuf[u]);
-            }
-        }
-    }
+template <int C, int PASS, int MODE, bool FULL>
+__global__ void __launch_bounds__(NT) k_scan(ScanArgs a)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    scan_body<C, PASS, MODE, FULL>(a, a.out, blockIdx.x * (NT / 64) + wv);
+}
+
+// left->right into a.out and right->left into a.out_b, concurrently (blockIdx.y picks the pass)
+template <int C, bool FULL>
+__global__ void __launch_bounds__(NT) k_scan_lr(ScanArgs a)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int line = blockIdx.x * (NT / 64) + wv;
+    if (blockIdx.y == 0) scan_body<C, 0, 0, FULL>(a, a.out, line);
+    else scan_body<C, 1, 0, FULL>(a, a.out_b, line);
 }
 
 }  // namespace
@@ -189,6 +257,7 @@ __global__ void __launch_bounds__(NT) k_scan(ScanArgs a)
 struct smt_scanline {
     int H, W, D, p1, p2;
     hipStream_t stream;
+    float *scratch;      // one [H][W][D] volume: the right path until the up pass consumes it
 };
 
 SMT_API int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanline **out)
@@ -196,13 +265,14 @@ SMT_API int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanlin
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_scanline *h = new (std::nothrow) smt_scanline();
     if (!h) return SMT_ERR_ALLOC;
-    h->H = H; h->W = W; h->D = D; h->p1 = p1; h->p2 = p2; h->stream = nullptr;
+    h->H = H; h->W = W; h->D = D; h->p1 = p1; h->p2 = p2; h->stream = nullptr; h->scratch = nullptr;
     *out = h;
     return SMT_OK;
 }
 SMT_API int smt_scanline_destroy(smt_scanline *h)
 {
     if (!h) return SMT_ERR_ARG;
+    if (h->scratch) (void)hipFree(h->scratch);
     delete h;
     return SMT_OK;
 }
@@ -213,28 +283,51 @@ SMT_API int smt_scanline_set_stream(smt_scanline *h, void *s)
     return SMT_OK;
 }
 
-template <int C>
-static void launch_scan(smt_scanline *h, int pass, const ScanArgs &a)
+template <int C, int MODE, bool FULL>
+static void launch_scan2(smt_scanline *h, int pass, const ScanArgs &a)
 {
     const int nlines = pass < 2 ? h->H : h->W;
     dim3 grid((nlines + 3) / 4);
     switch (pass) {
-    case 0: hipLaunchKernelGGL((k_scan<C, 0>), grid, dim3(NT), 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_scan<C, 1>), grid, dim3(NT), 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_scan<C, 2>), grid, dim3(NT), 0, h->stream, a); break;
-    default: hipLaunchKernelGGL((k_scan<C, 3>), grid, dim3(NT), 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((k_scan<C, 0, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_scan<C, 1, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_scan<C, 2, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
+    default: hipLaunchKernelGGL((k_scan<C, 3, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
     }
 }
 
-static int scan_pass(smt_scanline *h, const float *vin, const float *gray, int pass, float *vout,
-                     int accumulate, float *disp)
+template <int C>
+static void launch_scan(smt_scanline *h, int pass, const ScanArgs &a, int mode)
 {
-    ScanArgs a{vin, gray, vout, disp, h->H, h->W, h->D, (float)h->p1, (float)h->p2, accumulate};
+    const bool full = (h->D == 64 * C);
+    if (full) {
+        if (mode == 0) launch_scan2<C, 0, true>(h, pass, a);
+        else if (mode == 1) launch_scan2<C, 1, true>(h, pass, a);
+        else if (mode == 2) launch_scan2<C, 2, true>(h, pass, a);
+        else launch_scan2<C, 3, true>(h, pass, a);
+    } else {
+        if (mode == 0) launch_scan2<C, 0, false>(h, pass, a);
+        else if (mode == 1) launch_scan2<C, 1, false>(h, pass, a);
+        else if (mode == 2) launch_scan2<C, 2, false>(h, pass, a);
+        else launch_scan2<C, 3, false>(h, pass, a);
+    }
+}
+
+template <int C>
+static void launch_lr(smt_scanline *h, const ScanArgs &a)
+{
+    dim3 grid((h->H + 3) / 4, 2);
+    if (h->D == 64 * C) hipLaunchKernelGGL((k_scan_lr<C, true>), grid, dim3(NT), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_scan_lr<C, false>), grid, dim3(NT), 0, h->stream, a);
+}
+
+static int scan_pass(smt_scanline *h, const ScanArgs &a, int pass, int mode)
+{
     switch ((h->D + 63) / 64) {
-    case 1: launch_scan<1>(h, pass, a); break;
-    case 2: launch_scan<2>(h, pass, a); break;
-    case 3: launch_scan<3>(h, pass, a); break;
-    default: launch_scan<4>(h, pass, a); break;
+    case 1: launch_scan<1>(h, pass, a, mode); break;
+    case 2: launch_scan<2>(h, pass, a, mode); break;
+    case 3: launch_scan<3>(h, pass, a, mode); break;
+    default: launch_scan<4>(h, pass, a, mode); break;
     }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -243,15 +336,27 @@ static int scan_pass(smt_scanline *h, const float *vin, const float *gray, int p
 SMT_API int smt_scanline_pass(smt_scanline *h, const float *vin, const float *gray, int pass, float *vout)
 {
     if (!h || !vin || !gray || !vout || vin == vout || pass < 0 || pass > 3) return SMT_ERR_ARG;
-    return scan_pass(h, vin, gray, pass, vout, 0, nullptr);
+    ScanArgs a{vin, gray, vout, nullptr, nullptr, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2, 0};
+    return scan_pass(h, a, pass, 0);
 }
 
 SMT_API int smt_scanline_run(smt_scanline *h, const float *vin, const float *gray, float *vout, float *disp)
 {
     if (!h || !vin || !gray || !vout || vin == vout) return SMT_ERR_ARG;
-    int rc = scan_pass(h, vin, gray, 0, vout, 0, nullptr);                 // left
-    if (rc == SMT_OK) rc = scan_pass(h, vin, gray, 1, vout, 1, nullptr);   // (left + right)
-    if (rc == SMT_OK) rc = scan_pass(h, vin, gray, 2, vout, 1, nullptr);   // (..) + up
-    if (rc == SMT_OK) rc = scan_pass(h, vin, gray, 3, vout, 1, disp);      // (..) + down, fused WTA
-    return rc;
+    if (!h->scratch) {
+        int rc = smt_malloc((void **)&h->scratch, (size_t)h->H * h->W * h->D * 4);
+        if (rc != SMT_OK) return rc;
+    }
+    ScanArgs a{vin, gray, vout, h->scratch, h->scratch, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2, 0};
+    switch ((h->D + 63) / 64) {                                            // left -> vout, right -> scratch
+    case 1: launch_lr<1>(h, a); break;
+    case 2: launch_lr<2>(h, a); break;
+    case 3: launch_lr<3>(h, a); break;
+    default: launch_lr<4>(h, a); break;
+    }
+    SMT_LAUNCH_CHECK();
+    int rc = scan_pass(h, a, 2, 3);                                        // vout = (left + right) + up
+    if (rc != SMT_OK) return rc;
+    a.disp = disp;
+    return scan_pass(h, a, 3, disp ? 2 : 1);                               // vout = (..) + down [+ WTA]
 }

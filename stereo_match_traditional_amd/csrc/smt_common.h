@@ -71,17 +71,19 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 // order-preserving map float -> uint32 (handles negatives; NaNs are not ordered)
 __device__ __forceinline__ unsigned f32_key(float f)
 {
-    const unsigned b = __float_as_uint(f);
+    const unsigned b = __float_as_uint(f + 0.0f);          // -0 -> +0 so that equal zeros tie
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
 // First-strict-minimum WTA across a wave whose lanes hold candidates in increasing-d
-// order: (v, d) = this lane's first local minimum.  Returns the winning d in every lane.
+// order: (v, d) = this lane's first local minimum (v = +inf for lanes with no candidate).
+// Returns the winning d, wave-uniform.  All 64 lanes must be active.
 __device__ __forceinline__ int wave_argmin_first(float v, int d)
 {
-    const float m = wave_min_f32(v);
-    const unsigned long long b = __ballot(v == m);
-    const int first = __ffsll((long long)b) - 1;
-    return __shfl(d, first, WAVE);
+    const unsigned key = f32_key(v);
+    const unsigned m = wave_min_u32(key);
+    const unsigned long long b = __ballot(key == m);
+    const int first = __builtin_ctzll(b);
+    return __builtin_amdgcn_readlane(d, first);
 }
 #endif
