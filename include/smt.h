@@ -176,6 +176,10 @@ int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, i
 int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out, int order,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising */
+/* Test / tuning hook: which aggregation kernel runs.  0 = pipelined one-wave-per-pixel walk
+ * (default), 1 = plain one-wave-per-pixel walk, 2 = LDS-staged 16-pixel workgroups (D % 4 == 0,
+ * falls back to 0 otherwise).  All three produce identical bits. */
+int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 
 /* CBLSM.h:327-381 ComputeAD / ComputeADRight on uchar images -> float volume. */
 int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int view, float *vol,

@@ -240,6 +240,10 @@ class CrossArmAggregation:
     def WTA(self, AggredCostVolume, disp):
         wta(AggredCostVolume, disp)
 
+    def set_variant(self, variant):
+        """0 pipelined walk (default), 1 plain walk, 2 LDS-staged workgroups."""
+        check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
+
     def status(self):
         check(lib().smt_crossarm_status(self._h), "smt_crossarm_status")
 

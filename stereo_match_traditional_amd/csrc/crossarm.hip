@@ -187,6 +187,209 @@ __global__ void __launch_bounds__(NT) k_aggregate(const float *__restrict__ vin,
     }
 }
 
+// ---- pipelined direct aggregation --------------------------------------------------------
+// One wave per pixel as above, but the rectangle walk is wave-uniform (scalar counters), so
+// the loads of the next U taps are issued before the U in-order adds: U*64*C*4 bytes in
+// flight per wave instead of one tap.  Out-of-plane taps (reference UB) contribute nothing
+// and raise the flag.
+constexpr int AU = 8;
+
+template <int C, int ORDER, bool FULL>
+__global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__ vin, float *__restrict__ vout,
+                                                       int H, int W, int D, const int *__restrict__ armL,
+                                                       const int *__restrict__ armR, const int *__restrict__ armT,
+                                                       const int *__restrict__ armB, float *__restrict__ disp,
+                                                       int *ub_flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = H * W;
+    const int p = blockIdx.x * (NT / 64) + wv;
+    if (p >= N) return;
+    const int Ll = __builtin_amdgcn_readfirstlane(armL[p]), Rr = __builtin_amdgcn_readfirstlane(armR[p]);
+    const int up = __builtin_amdgcn_readfirstlane(armT[p]), dn = __builtin_amdgcn_readfirstlane(armB[p]);
+    const int dl = lane * C;
+    // inner/outer extents and flat strides of the walk
+    const int nI = (ORDER == 0) ? (up + dn + 1) : (Ll + Rr + 1);
+    const int nO = (ORDER == 0) ? (Ll + Rr + 1) : (up + dn + 1);
+    const int sI = (ORDER == 0) ? W : 1, sO = (ORDER == 0) ? 1 : W;
+    const int total = nI * nO;
+    int idx = p - Ll - up * W;                 // first tap (both orders start at the top-left corner)
+    int inner = 0;
+    const int wrap = sO - nI * sI;             // from the last inner position to the next outer start
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.0f;
+    bool ub = false;
+    const float *base = vin + dl;
+
+    for (int n0 = 0; n0 < total; n0 += AU) {
+        float x[AU][C];
+        bool ok[AU];
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const bool in_rect = (n0 + u < total);
+            const bool in_plane = (idx >= 0 && idx < N);
+            ok[u] = in_rect && in_plane;
+            ub = ub || (in_rect && !in_plane);
+            const float *src = base + (size_t)(ok[u] ? idx : p) * D;
+            if (FULL) {
+                const vecf<C> v = *reinterpret_cast<const vecf<C> *>(src);
+#pragma unroll
+                for (int k = 0; k < C; k++) x[u][k] = v.v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k++) x[u][k] = (dl + k < D) ? src[k] : 0.0f;
+            }
+            // advance the walk (scalar)
+            inner++;
+            idx += sI;
+            if (inner == nI) { inner = 0; idx += wrap; }
+        }
+#pragma unroll
+        for (int u = 0; u < AU; u++)
+            if (ok[u]) {
+#pragma unroll
+                for (int k = 0; k < C; k++) acc[k] = acc[k] + x[u][k];
+            }
+    }
+    const float cnt = (float)total;
+    float best = INFINITY; int bk = 0;
+    float *dst = vout + (size_t)p * D + dl;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        acc[k] = acc[k] / cnt;
+        if (FULL || dl + k < D) {
+            dst[k] = acc[k];
+            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
+        }
+    }
+    if (ub && lane == 0) atomicOr(ub_flag, 1);
+    if (disp) {
+        if (!FULL && dl >= D) best = INFINITY;
+        const int wd = wave_argmin_first(best, dl + bk);
+        if (lane == 0) disp[p] = (float)wd;
+    }
+}
+
+// ---- LDS-staged aggregation ---------------------------------------------------------------
+// APB adjacent pixels per workgroup, one wave each (lanes = disparities, C per lane).  The
+// rectangles of adjacent pixels overlap almost completely, so the workgroup walks the union
+// of their rectangles in the reference's outer/inner order and stages every line segment
+// (up to RCH consecutive inner positions of one outer position, D floats each) ONCE in LDS;
+// each wave then adds the part of the segment that lies inside its own rectangle, in order.
+// Addresses are flat (p0 + o*so + n*si), which reproduces the reference's wrap across row
+// ends ((i+top)*col + j + left, CrossArm.cpp:92) without special cases.
+//   ORDER 0 (AggregationVertical): outer = column offset (stride 1), inner = row (stride W)
+//   ORDER 1 (costAggregationV5)  : outer = row (stride W),    inner = column (stride 1)
+constexpr int APB = 16;           // pixels (waves) per workgroup
+constexpr int RCH = 16;           // staged inner positions per segment
+constexpr int ANT = APB * 64;
+
+template <int C, int ORDER>
+__global__ void __launch_bounds__(ANT) k_aggregate_lds(const float *__restrict__ vin, float *__restrict__ vout,
+                                                       int H, int W, int D, const int *__restrict__ armL,
+                                                       const int *__restrict__ armR, const int *__restrict__ armT,
+                                                       const int *__restrict__ armB, float *__restrict__ disp,
+                                                       int *ub_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_buf[];      // [2][RCH][D]
+    __shared__ int s_rng[APB][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = H * W;
+    const int p0 = blockIdx.x * APB;
+    const int p = p0 + w;
+    const bool live = p < N;
+
+    // this wave's rectangle as [oa,ob] x [ia,ib] relative to p0
+    int oa = 1, ob = 0, ia = 1, ib = 0, cnt = 1;
+    if (live) {
+        const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
+        cnt = (Ll + Rr + 1) * (up + dn + 1);
+        if (ORDER == 0) { oa = w - Ll; ob = w + Rr; ia = -up; ib = dn; }
+        else            { oa = -up;    ob = dn;     ia = w - Ll; ib = w + Rr; }
+    }
+    if (lane == 0) { s_rng[w][0] = oa; s_rng[w][1] = ob; s_rng[w][2] = ia; s_rng[w][3] = ib; }
+    __syncthreads();
+    int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
+#pragma unroll
+    for (int k = 0; k < APB; k++) {
+        if (s_rng[k][0] <= s_rng[k][1]) {
+            omin = min(omin, s_rng[k][0]); omax = max(omax, s_rng[k][1]);
+            imin = min(imin, s_rng[k][2]); imax = max(imax, s_rng[k][3]);
+        }
+    }
+    const long so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
+    const int nin = imax - imin + 1;
+    const int nch = (nin + RCH - 1) / RCH;               // chunks per outer position
+    const int nseg = (omax - omin + 1) * nch;
+    const int D4 = D >> 2;                               // D % 4 == 0 on this path
+    const int dl = lane * C;
+
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.0f;
+    // flat indices grow with both o and n: the rectangle leaves the plane iff a corner does
+    const bool ub = live && ((long)p0 + oa * so + (long)ia * si < 0 || (long)p0 + ob * so + (long)ib * si >= N);
+
+    // each thread stages at most one float4 per segment (RCH * D4 <= ANT for D <= 256)
+    const int sl = tid / D4, sq = tid - sl * D4;         // staged line, float4 within the line
+    float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int seg) {
+        const int o = omin + seg / nch, n0 = imin + (seg % nch) * RCH;
+        stage = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sl < RCH && n0 + sl <= imax) {
+            const long idx = (long)p0 + o * so + (long)(n0 + sl) * si;
+            // lines of the union box that lie outside the plane are staged as zeros; whether a
+            // rectangle really uses one is decided per wave below
+            if (idx >= 0 && idx < N) stage = *reinterpret_cast<const float4 *>(vin + idx * D + 4 * sq);
+        }
+    };
+    auto commit = [&](int seg) {
+        if (sl < RCH) *reinterpret_cast<float4 *>(s_buf + (size_t)(seg & 1) * RCH * D + sl * D + 4 * sq) = stage;
+    };
+
+    if (nseg > 0) { fetch(0); commit(0); }
+    __syncthreads();
+    for (int seg = 0; seg < nseg; seg++) {
+        if (seg + 1 < nseg) fetch(seg + 1);              // global loads in flight during the adds
+        const int o = omin + seg / nch, n0 = imin + (seg % nch) * RCH;
+        if (o >= oa && o <= ob) {
+            const int a = max(n0, ia), b = min(n0 + RCH - 1, ib);
+            const float *src = s_buf + (size_t)(seg & 1) * RCH * D + dl;
+            for (int n = a; n <= b; n++) {
+                const float *r = src + (n - n0) * D;
+#pragma unroll
+                for (int k = 0; k < C; k++)
+                    if (dl + k < D) acc[k] = acc[k] + r[k];
+            }
+        }
+        if (seg + 1 < nseg) commit(seg + 1);
+        __syncthreads();
+    }
+
+    if (__syncthreads_or(ub) && tid == 0) atomicOr(ub_flag, 1);
+    if (!live) return;
+    const float fc = (float)cnt;
+    float best = INFINITY; int bk = 0;
+    float *dst = vout + (size_t)p * D + dl;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        acc[k] = acc[k] / fc;
+        if (dl + k < D) {
+            dst[k] = acc[k];
+            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
+        }
+    }
+    if (disp) {
+        if (dl >= D) best = INFINITY;
+        const int wd = wave_argmin_first(best, dl + bk);
+        if (lane == 0) disp[p] = (float)wd;
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_cblsm_ad(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R,
                                                  int H, int W, int D, int view, float *__restrict__ vol)
 {
@@ -217,6 +420,7 @@ struct smt_crossarm {
     int *arm[4];
     int *flip;     // 4 flip indices + 1 UB flag
     bool have_arms;
+    int variant;         // aggregation kernel variant (test / tuning hook)
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -299,6 +503,50 @@ SMT_API int smt_crossarm_arm_maps(smt_crossarm *h, int **l, int **r, int **t, in
 }
 
 template <int ORDER>
+static void launch_agg_lds(smt_crossarm *h, const float *vin, float *vout, float *disp)
+{
+    const int N = h->H * h->W;
+    dim3 grid((N + APB - 1) / APB);
+    const int C = (h->D + 63) / 64;
+    const size_t shm = (size_t)2 * RCH * h->D * 4;
+    int *ub = h->flip + 4;
+#define SMT_AGGL(CC)                                                                                     \
+    hipLaunchKernelGGL((k_aggregate_lds<CC, ORDER>), grid, dim3(ANT), shm, h->stream, vin, vout, h->H, h->W, \
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub)
+    switch (C) {
+    case 1: SMT_AGGL(1); break;
+    case 2: SMT_AGGL(2); break;
+    case 3: SMT_AGGL(3); break;
+    default: SMT_AGGL(4); break;
+    }
+#undef SMT_AGGL
+}
+
+template <int ORDER>
+static void launch_agg_pipe(smt_crossarm *h, const float *vin, float *vout, float *disp)
+{
+    const int N = h->H * h->W;
+    dim3 grid((N + 3) / 4);
+    const int C = (h->D + 63) / 64;
+    const bool full = (h->D == 64 * C);
+    int *ub = h->flip + 4;
+#define SMT_AGGP(CC, FF)                                                                                  \
+    hipLaunchKernelGGL((k_aggregate_pipe<CC, ORDER, FF>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub)
+    switch (C * 2 + (full ? 1 : 0)) {
+    case 2: SMT_AGGP(1, false); break;
+    case 3: SMT_AGGP(1, true); break;
+    case 4: SMT_AGGP(2, false); break;
+    case 5: SMT_AGGP(2, true); break;
+    case 6: SMT_AGGP(3, false); break;
+    case 7: SMT_AGGP(3, true); break;
+    case 8: SMT_AGGP(4, false); break;
+    default: SMT_AGGP(4, true); break;
+    }
+#undef SMT_AGGP
+}
+
+template <int ORDER>
 static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
     const int N = h->H * h->W;
@@ -321,9 +569,20 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    if (order == 0) launch_agg<0>(h, vin, vout, disp);
-    else launch_agg<1>(h, vin, vout, disp);
+    // variant: 0 = pipelined direct (default), 1 = simple direct, 2 = LDS-staged (D % 4 == 0)
+    int variant = h->variant;
+    if (variant == 2 && (h->D % 4)) variant = 0;
+    if (variant == 2) { if (order == 0) launch_agg_lds<0>(h, vin, vout, disp); else launch_agg_lds<1>(h, vin, vout, disp); }
+    else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
+    else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
+{
+    if (!h || variant < 0 || variant > 2) return SMT_ERR_ARG;
+    h->variant = variant;
     return SMT_OK;
 }
 

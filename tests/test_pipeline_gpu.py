@@ -92,9 +92,13 @@ AGG_CASES = [(72, 160, 16, "synth", 3), (64, 150, 64, "smooth", 5), (72, 160, 10
              (48, 180, 192, "synth", 8)]
 
 
+AGG_CASES += [(70, 155, 60, "smooth", 12), (66, 149, 7, "synth", 13)]   # W % 16 != 0, D % 4 != 0
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("H,W,D,kind,seed", AGG_CASES)
 @pytest.mark.parametrize("order", [0, 1])
-def test_aggregation(smt, O, H, W, D, kind, seed, order):
+def test_aggregation(smt, O, H, W, D, kind, seed, order, variant):
     img = _img(H, W, kind, seed, O)
     vol = np.random.default_rng(seed).random((H, W, D), dtype=np.float32) * 2
     style = "adcensus" if order == 0 else "cblsm"
@@ -105,6 +109,7 @@ def test_aggregation(smt, O, H, W, D, kind, seed, order):
     ref, oob = O.aggregate_rect(vol, arms, order)
     assert oob == 0, "test size must not trigger the reference's out-of-plane reads"
     ca = smt.CrossArmAggregation().Initialize(H, W, 30 if order == 0 else 25, D, DEV, style=style)
+    ca.set_variant(variant)
     ca.ComputeArmLengths(T(img))
     out = torch.empty((H, W, D), device=DEV)
     disp = torch.empty((H, W), device=DEV)

@@ -49,6 +49,12 @@ def pipeline(H, W, D, seed, noise, reps):
     res["mean_rect_area_left"] = float(area.mean())
     aggL = torch.empty((H, W, D), device=DEV)
     aggR = torch.empty((H, W, D), device=DEV)
+    rL, rR, rT, rB = [a.float() for a in caR.arm_maps()]
+    res["mean_rect_area_right"] = float(((rL + rR + 1) * (rT + rB + 1)).mean())
+    for v in (1, 2):
+        caL.set_variant(v)
+        res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
+    caL.set_variant(0)
     res["aggregate_L_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     res["aggregate_R_ms"] = timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), max(1, reps // 4))
     caL.status()
