@@ -29,7 +29,7 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(H, W, D, seed, rows=64):
+def cpu_baseline(H, W, D, seed, rows=256):
     """Oracle (CPU 'port' of AD-Census.h:271-380), 1 thread, on a band of `rows` rows of the
     SAME workload, both views + WTA.  Only this function touches oracle/."""
     from oracle import oracle as orc
@@ -49,6 +49,19 @@ def cpu_baseline(H, W, D, seed, rows=64):
                       f"both views + WTA, {dt:.1f} s, gcc -O2, 1 thread)"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per pair of the cost kernel (both launches) from the committed rocprofv3 PMC
+    passes (profiles/pmc_traffic.json, written by tools/pmc_traffic.py from separate
+    FETCH_SIZE / WRITE_SIZE runs with the gfx950 corrections of MI355X_MICROARCH.md).  PMC
+    cannot be collected from inside an un-profiled run, so this is the last profiled value."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))[workload]
+        return rec["hbm_bytes_per_pair"], rec["source"]
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="adcensus_1080p_d192", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs-per-step", type=int, default=1)
-    ap.add_argument("--cpu-rows", type=int, default=64, help="rows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=256, help="rows in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,11 +114,10 @@ def main():
     for _ in range(args.steps):
         step()
     if world > 1:
-        # config 5's only exchange: gather the disparity maps, all-reduce a checksum
-        gathered = [torch.empty_like(dl) for _ in range(world)]
-        dist.all_gather(gathered, dl)
-        chk = dl.sum(dtype=torch.float64)
-        dist.all_reduce(chk)
+        # config 5's only exchange: gather the disparity maps, all-reduce a checksum (shard.py)
+        from stereo_match_traditional_amd import shard
+        shard.gather_disparities(dl, world * P)
+        shard.checksum(dl)
     barrier()
     dt = time.perf_counter() - t0
     prep_ms, cost_ms = adc.kernel_times()
@@ -125,6 +137,7 @@ def main():
         alg_bytes = 8.0 * hyp_pair
         k_ms = float(np.mean(cost_ms)) if cost_ms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload)
         out = {
             "metric": "Mdisparities/s (HxWxD/s) + ms/pair, AD-Census 1920x1080 D=192",
             "value": round(value, 2),
@@ -142,7 +155,7 @@ def main():
             "config": {"workload": f"AD-Census 9x7 both views + WTA, {W}x{H} D={D} ({args.workload})",
                        "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_cost (cost volume + fused WTA, both views)",
                          "kernel_ms": round(k_ms, 4), "tables_ms": round(float(np.mean(prep_ms)), 4),
                          "algorithmic_bytes_per_launch": alg_bytes},

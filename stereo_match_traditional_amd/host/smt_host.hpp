@@ -1,0 +1,268 @@
+// smt_host.hpp -- C++ host-side mirror of the reference's classes over the C ABI (smt.h).
+//
+// Same class names, method names, argument order and HOST-pointer ownership as the
+// reference (AD-CensusV1/{AD-Census.h,CrossArm.h,ScanlineOptimizer.h,PostProcessing.h},
+// CBLSM/cross_aggregator.h), so that the reference's main()s compile against this header
+// instead of their own after dropping the cv::Mat arguments.  Every
+// method uploads / downloads through smt_memcpy_* and runs the HIP kernels of
+// libsmt_hip.so; there is no CPU implementation behind it.
+//
+// Deviations (all forced by the missing OpenCV dependency, none changes results):
+//   - cv::Mat parameters become (const unsigned char* data, int channels).
+//   - Errors: the reference returns void and has UB on bad input; these methods throw
+//     std::runtime_error carrying smt_strerror().
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/smt.h"
+
+namespace smt {
+
+inline void check(int rc, const char *what)
+{
+    if (rc != SMT_OK) throw std::runtime_error(std::string(what) + ": " + smt_strerror(rc));
+}
+
+// RAII device buffer
+template <class T> class DevBuf {
+public:
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { resize(n); }
+    ~DevBuf() { if (p_) smt_free(p_); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void resize(size_t n)
+    {
+        if (p_) smt_free(p_);
+        p_ = nullptr; n_ = n;
+        void *q = nullptr;
+        check(smt_malloc(&q, n * sizeof(T)), "smt_malloc");
+        p_ = static_cast<T *>(q);
+    }
+    void upload(const T *h) { check(smt_memcpy_h2d(p_, h, n_ * sizeof(T), nullptr), "h2d"); }
+    void download(T *h) const
+    {
+        check(smt_memcpy_d2h(h, p_, n_ * sizeof(T), nullptr), "d2h");
+        check(smt_stream_sync(nullptr), "sync");
+    }
+    T *get() const { return p_; }
+    size_t size() const { return n_; }
+private:
+    T *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ------------------------------------------------------------------ AD-Census.h:9-43
+class AD_Census {
+public:
+    AD_Census() = default;
+    ~AD_Census() { if (h_) smt_adcensus_destroy(h_); }
+    // Initialize(leftImage, rightImage, dispRange, row, col, LImage, RImage, sigmaC, sigmaS)
+    void Initialize(float *leftImage, float *rightImage, int dispRange, int row, int col, float sigmaC,
+                    float sigmaS)
+    {
+        row_ = row; col_ = col; D_ = dispRange;
+        if (h_) { smt_adcensus_destroy(h_); h_ = nullptr; }
+        check(smt_adcensus_create(row, col, dispRange, sigmaC, sigmaS, &h_), "smt_adcensus_create");
+        L_.resize((size_t)row * col); R_.resize((size_t)row * col);
+        L_.upload(leftImage); R_.upload(rightImage);
+        hostL_.assign((size_t)row * col * dispRange, 0.f);
+        hostR_.assign((size_t)row * col * dispRange, 0.f);
+        validL_ = validR_ = false;
+    }
+    void ComputeADcensus() { check(smt_adcensus_compute(h_, L_.get(), R_.get(), SMT_VIEW_LEFT, nullptr, nullptr), "compute"); validL_ = false; }
+    void ComputeADcensusRight() { check(smt_adcensus_compute(h_, L_.get(), R_.get(), SMT_VIEW_RIGHT, nullptr, nullptr), "compute"); validR_ = false; }
+    // device-side volume (borrowed), for chaining into CrossArmAggregation without a round trip
+    float *DevicePtrLeft() { float *p; check(smt_adcensus_volume(h_, SMT_VIEW_LEFT, &p), "volume"); return p; }
+    float *DevicePtrRight() { float *p; check(smt_adcensus_volume(h_, SMT_VIEW_RIGHT, &p), "volume"); return p; }
+    // GetPtrLeft/Right: host copy of the cost volume, valid for the object's life like the reference's
+    float *GetPtrLeft()
+    {
+        if (!validL_) { fetch(DevicePtrLeft(), hostL_); validL_ = true; }
+        return hostL_.data();
+    }
+    float *GetPtrRight()
+    {
+        if (!validR_) { fetch(DevicePtrRight(), hostR_); validR_ = true; }
+        return hostR_.data();
+    }
+    void WTA(float *leftdisp, float *rightDisp)
+    {
+        const size_t n = (size_t)row_ * col_;
+        DevBuf<float> dl(n), dr(n);
+        check(smt_wta(DevicePtrLeft(), row_, col_, D_, dl.get(), nullptr), "wta");
+        check(smt_wta(DevicePtrRight(), row_, col_, D_, dr.get(), nullptr), "wta");
+        dl.download(leftdisp); dr.download(rightDisp);
+        check(smt_adcensus_status(h_), "smt_adcensus_status");
+    }
+private:
+    void fetch(const float *dev, std::vector<float> &host)
+    {
+        check(smt_memcpy_d2h(host.data(), dev, host.size() * sizeof(float), nullptr), "d2h");
+        check(smt_stream_sync(nullptr), "sync");
+    }
+    smt_adcensus *h_ = nullptr;
+    int row_ = 0, col_ = 0, D_ = 0;
+    DevBuf<float> L_, R_;
+    std::vector<float> hostL_, hostR_;
+    bool validL_ = false, validR_ = false;
+};
+
+// ------------------------------------------------------------------ CrossArm.h:9-36
+class CrossArmAggregation {
+public:
+    CrossArmAggregation() = default;
+    ~CrossArmAggregation() { if (h_) smt_crossarm_destroy(h_); }
+    void Initialize(int row, int col, float * /*leftImage*/, float * /*rightImage*/, int tao, int dispRange)
+    {
+        row_ = row; col_ = col; D_ = dispRange;
+        if (h_) { smt_crossarm_destroy(h_); h_ = nullptr; }
+        smt_crossarm_params p;
+        smt_crossarm_default_params(&p);
+        p.tau = tao;
+        check(smt_crossarm_create(row, col, dispRange, &p, &h_), "smt_crossarm_create");
+    }
+    // The four Compute*ArmLength(const Mat&) calls of main.cpp:69-72 always come together and in
+    // this order (the threshold state chains through them), so they are one call here.
+    void ComputeArmLengths(const unsigned char *image, int channels)
+    {
+        DevBuf<unsigned char> img((size_t)row_ * col_ * channels);
+        img.upload(image);
+        check(smt_crossarm_arms(h_, img.get(), channels), "smt_crossarm_arms");
+        check(smt_stream_sync(nullptr), "sync");
+    }
+    void AggregationVertical(float *dispVolume, float *aggregatedCostVolume)
+    {
+        const size_t V = (size_t)row_ * col_ * D_;
+        DevBuf<float> in(V), out(V);
+        in.upload(dispVolume);
+        AggregationVerticalDevice(in.get(), out.get());
+        out.download(aggregatedCostVolume);
+        check(smt_crossarm_status(h_), "smt_crossarm_status");
+    }
+    void AggregationVerticalDevice(const float *dev_in, float *dev_out, float *dev_disp = nullptr)
+    {
+        check(smt_crossarm_aggregate(h_, dev_in, dev_out, 0, dev_disp), "smt_crossarm_aggregate");
+    }
+    void WTA(float *AggredCostVolume, float *disp)
+    {
+        const size_t n = (size_t)row_ * col_;
+        DevBuf<float> v(n * D_), d(n);
+        v.upload(AggredCostVolume);
+        check(smt_wta(v.get(), row_, col_, D_, d.get(), nullptr), "wta");
+        d.download(disp);
+    }
+private:
+    smt_crossarm *h_ = nullptr;
+    int row_ = 0, col_ = 0, D_ = 0;
+};
+
+// ------------------------------------------------------------------ ScanlineOptimizer.h:8-34
+class ScanlineOptimizer {
+public:
+    ScanlineOptimizer() = default;
+    ~ScanlineOptimizer() { if (h_) smt_scanline_destroy(h_); }
+    void Initialize(int row, int col, int dispRange, float * /*costVolume*/, int p1, int p2)
+    {
+        row_ = row; col_ = col; D_ = dispRange;
+        if (h_) { smt_scanline_destroy(h_); h_ = nullptr; }
+        check(smt_scanline_create(row, col, dispRange, p1, p2, &h_), "smt_scanline_create");
+        processed_.resize((size_t)row * col * dispRange);
+    }
+    void ScanLine(float *costVolume, float *Image)
+    {
+        const size_t n = (size_t)row_ * col_;
+        DevBuf<float> in(n * D_), g(n);
+        in.upload(costVolume); g.upload(Image);
+        check(smt_scanline_run(h_, in.get(), g.get(), processed_.get(), nullptr), "smt_scanline_run");
+        check(smt_stream_sync(nullptr), "sync");
+    }
+    void WTA(float *disp)
+    {
+        DevBuf<float> d((size_t)row_ * col_);
+        check(smt_wta(processed_.get(), row_, col_, D_, d.get(), nullptr), "wta");
+        d.download(disp);
+    }
+    float *DeviceProcessedVolume() { return processed_.get(); }
+private:
+    smt_scanline *h_ = nullptr;
+    int row_ = 0, col_ = 0, D_ = 0;
+    DevBuf<float> processed_;
+};
+
+// ------------------------------------------------------------------ PostProcessing.h:72
+inline void LeftRightConsistency(int col, int row, int gate, float *leftDisp, float *rightDisp,
+                                 std::vector<std::pair<int, int>> &occlusion,
+                                 std::vector<std::pair<int, int>> &mismatch)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<float> dl(n), dr(n);
+    DevBuf<uint8_t> cls(n);
+    dl.upload(leftDisp); dr.upload(rightDisp);
+    check(smt_lrcheck(dl.get(), dr.get(), row, col, gate, cls.get(), nullptr, nullptr), "smt_lrcheck");
+    dl.download(leftDisp);
+    std::vector<uint8_t> h(n);
+    cls.download(h.data());
+    std::vector<int> o(2 * n), m(2 * n);
+    int no = 0, nm = 0;
+    check(smt_lrcheck_lists(h.data(), row, col, o.data(), &no, m.data(), &nm), "smt_lrcheck_lists");
+    occlusion.clear(); mismatch.clear();
+    for (int k = 0; k < no; k++) occlusion.emplace_back(o[2 * k], o[2 * k + 1]);
+    for (int k = 0; k < nm; k++) mismatch.emplace_back(m[2 * k], m[2 * k + 1]);
+}
+
+// ------------------------------------------------------------------ cross_aggregator.h:27-113
+struct CrossArm { uint8_t left, right, top, bottom; };
+
+class CrossAggregator {
+public:
+    CrossAggregator() = default;
+    ~CrossAggregator() { if (h_) smt_crossagg_destroy(h_); }
+    bool Initialize(const int &width, const int &height, const int &min_disparity, const int &max_disparity)
+    {
+        w_ = width; hgt_ = height; D_ = max_disparity - min_disparity;
+        if (h_) { smt_crossagg_destroy(h_); h_ = nullptr; }
+        const int rc = smt_crossagg_create(width, height, D_, &h_);
+        if (rc == SMT_ERR_ARG) return false;            // reference returns false, :28-31
+        check(rc, "smt_crossagg_create");
+        return true;
+    }
+    void SetData(const uint8_t *img_left, const uint8_t * /*img_right*/, const float *cost_init)
+    {
+        img_ = img_left; cost_ = cost_init;
+    }
+    void SetParams(const int &L1, const int &L2, const int &t1, const int &t2)
+    {
+        if (h_) check(smt_crossagg_set_params(h_, L1, L2, t1, t2), "smt_crossagg_set_params");
+    }
+    void Aggregate(const int &num_iters)
+    {
+        if (!h_) return;                                 // :91-93
+        const size_t n = (size_t)w_ * hgt_;
+        DevBuf<uint8_t> img(n * 3);
+        DevBuf<float> c(n * D_);
+        img.upload(img_); c.upload(cost_);
+        check(smt_crossagg_aggregate(h_, img.get(), c.get(), num_iters), "smt_crossagg_aggregate");
+        host_cost_.resize(n * D_);
+        host_arms_.resize(n);
+        float *dc; uint8_t *da;
+        check(smt_crossagg_cost(h_, &dc), "cost"); check(smt_crossagg_arms(h_, &da), "arms");
+        check(smt_memcpy_d2h(host_cost_.data(), dc, n * D_ * 4, nullptr), "d2h");
+        check(smt_memcpy_d2h(host_arms_.data(), da, n * 4, nullptr), "d2h");
+        check(smt_stream_sync(nullptr), "sync");
+    }
+    CrossArm *get_arms_ptr() { return host_arms_.data(); }
+    float *get_cost_ptr() { return host_cost_.empty() ? nullptr : host_cost_.data(); }
+private:
+    smt_crossagg *h_ = nullptr;
+    int w_ = 0, hgt_ = 0, D_ = 0;
+    const uint8_t *img_ = nullptr;
+    const float *cost_ = nullptr;
+    std::vector<float> host_cost_;
+    std::vector<CrossArm> host_arms_;
+};
+
+}  // namespace smt
