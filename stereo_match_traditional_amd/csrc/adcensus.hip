@@ -45,93 +45,127 @@ struct Tables {
 // ---- tap validity mask + the four census tables --------------------------------------
 // bit layout: tap t = (r+4)*7 + (c+3), r in [-4,4] outer, c in [-3,3] inner, MSB first:
 // bit (62 - t)  (63 left shifts of a 64-bit word, AD-Census.h:171-172).
-__global__ void __launch_bounds__(256) k_prep(const float *__restrict__ Lf,
-                                              const float *__restrict__ Rf, int H, int W, Tables T)
-{
-    const int i = blockIdx.y;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. WX-1
-    const int WX = T.WX;
-    if (x >= WX) return;
-    const uint8_t *Lb = T.u8[0], *Rb = T.u8[1];
+//
+// Away from the left/right borders the extended tables equal the ordinary censuses:
+//   cenX_R[xr] == cenA_R[xr] for xr >= 3      (no neighbour column is clamped to 0)
+//   cenX_L[xl] == cenA_L[xl] for xl <= W-4    (no neighbour wraps to column 0, centre unclamped)
+// so k_prep computes the two ordinary censuses + mask once per pixel from LDS-staged rows and
+// writes them to both places; k_prep_edges fills the 6 + 7 special columns per row.
+constexpr int PTW = 256;                                    // pixels per workgroup (one row segment)
 
-    if (x < W) {
-        // anchor censuses + mask at pixel (i, x)
-        const int lc = Lb[i * W + x], rc = Rb[i * W + x];
-        uint64_t cl = 0, cr = 0, m = 0;
-#pragma unroll
-        for (int r = -4; r <= 4; r++) {
-            const int ii = i + r;
-            const bool rv = (ii >= 0 && ii < H);
-#pragma unroll
-            for (int c = -3; c <= 3; c++) {
-                cl <<= 1; cr <<= 1; m <<= 1;
-                const int jj = x + c;
-                if (rv && jj >= 0 && jj < W) {
-                    m |= 1;
-                    cl |= (uint64_t)(lc > (int)Lb[ii * W + jj]);
-                    cr |= (uint64_t)(rc > (int)Rb[ii * W + jj]);
-                }
-            }
-        }
-        T.cenA[0][(size_t)i * W + x] = cl;
-        T.cenA[1][(size_t)i * W + x] = cr;
-        T.mask[(size_t)i * W + x] = m;
-    }
-    // cenX_R at xr = x-3 in [-3, W-1] (table index x in [0, W+2])
-    if (x <= W + 2) {
-        const int xr = x - 3;
-        const int cc = xr < 0 ? 0 : xr;
-        const int rc = Rb[i * W + cc];
-        uint64_t w = 0;
-#pragma unroll
-        for (int r = -4; r <= 4; r++) {
-            const int ii = i + r;
-            const bool rv = (ii >= 0 && ii < H);
-#pragma unroll
-            for (int c = -3; c <= 3; c++) {
-                w <<= 1;
-                int jj = xr + c;
-                if (jj < 0) jj = 0;                      // left replicate (:177-178)
-                if (rv && jj < W) w |= (uint64_t)(rc > (int)Rb[ii * W + jj]);
-            }
-        }
-        T.cenX[0][(size_t)i * WX + x] = w;
-    }
-    // cenX_L at xl = x in [0, W+3]
-    if (x <= W + 3) {
-        const int cc = x > W - 1 ? W - 1 : x;            // centre clamps to W-1 (:224-225)
-        const int lc = Lb[i * W + cc];
-        uint64_t w = 0;
-#pragma unroll
-        for (int r = -4; r <= 4; r++) {
-            const int ii = i + r;
-            const bool rv = (ii >= 0 && ii < H);
-#pragma unroll
-            for (int c = -3; c <= 3; c++) {
-                w <<= 1;
-                int jj = x + c;
-                if (jj >= W) jj = 0;                     // neighbour wraps to column 0 (:242-243)
-                if (rv && jj >= 0) w |= (uint64_t)(lc > (int)Lb[ii * W + jj]);
-            }
-        }
-        T.cenX[1][(size_t)i * WX + x] = w;
-    }
+__device__ __forceinline__ unsigned to_u8_checked(float a, bool &bad)
+{
+    const int ia = (int)a;
+    bad = bad || !(a >= 0.0f && a <= 255.0f && (float)ia == a);
+    return (unsigned)ia & 0xffu;
 }
 
-// float image -> u8 image + domain check
-__global__ void __launch_bounds__(256) k_to_u8(const float *__restrict__ Lf,
-                                               const float *__restrict__ Rf, int n, uint8_t *Lb,
-                                               uint8_t *Rb, int *flag)
+__global__ void __launch_bounds__(PTW) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
+                                              int H, int W, Tables T)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float a = Lf[k], b = Rf[k];
-    const int ia = (int)a, ib = (int)b;
-    const bool bad = !(a >= 0.0f && a <= 255.0f && (float)ia == a) ||
-                     !(b >= 0.0f && b <= 255.0f && (float)ib == b);
-    Lb[k] = (uint8_t)ia;
-    Rb[k] = (uint8_t)ib;
-    if (bad) atomicOr(flag, 1);
+    __shared__ uint8_t sL[9][PTW + 8];
+    __shared__ uint8_t sR[9][PTW + 8];
+    const int i = blockIdx.y;
+    const int x0 = blockIdx.x * PTW;
+    const int tid = threadIdx.x;
+    // stage rows i-4..i+4, columns x0-3..x0+PTW+2 straight from the float images (coordinates
+    // clamped; out-of-image taps are masked); this also is the float -> u8 conversion + domain check
+    bool bad = false;
+    for (int e = tid; e < 9 * (PTW + 6); e += PTW) {
+        const int r = e / (PTW + 6), c = e - r * (PTW + 6);
+        int ii = i + r - 4, jj = x0 + c - 3;
+        ii = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+        jj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
+        sL[r][c] = (uint8_t)to_u8_checked(Lf[(size_t)ii * W + jj], bad);
+        sR[r][c] = (uint8_t)to_u8_checked(Rf[(size_t)ii * W + jj], bad);
+    }
+    if (__syncthreads_or(bad) && tid == 0) atomicOr(T.flag, 1);
+    const int x = x0 + tid;
+    if (x >= W) return;
+    T.u8[0][(size_t)i * W + x] = sL[4][tid + 3];
+    T.u8[1][(size_t)i * W + x] = sR[4][tid + 3];
+    // Branch-free: every staged byte is readable (coordinates were clamped at staging), the raw
+    // comparison bits are masked afterwards with the tap-validity word.  Bits are assembled in two
+    // 32-bit halves with compile-time positions (tap t -> bit 62-t).
+    const unsigned lc = sL[4][tid + 3], rc = sR[4][tid + 3];
+    unsigned clh = 0, cll = 0, crh = 0, crl = 0, mh = 0, ml = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int ii = i + r - 4;
+        const unsigned rv = (ii >= 0 && ii < H) ? 1u : 0u;
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            const int pos = 62 - (r * 7 + c);
+            const int jj = x + c - 3;
+            const unsigned v = rv & ((jj >= 0 && jj < W) ? 1u : 0u);
+            const unsigned bl = (lc > (unsigned)sL[r][tid + c]) ? 1u : 0u;
+            const unsigned br = (rc > (unsigned)sR[r][tid + c]) ? 1u : 0u;
+            if (pos >= 32) { clh |= bl << (pos - 32); crh |= br << (pos - 32); mh |= v << (pos - 32); }
+            else           { cll |= bl << pos;        crl |= br << pos;        ml |= v << pos; }
+        }
+    }
+    const uint64_t m = ((uint64_t)mh << 32) | ml;
+    const uint64_t cl = (((uint64_t)clh << 32) | cll) & m;
+    const uint64_t cr = (((uint64_t)crh << 32) | crl) & m;
+    const size_t p = (size_t)i * W + x;
+    T.cenA[0][p] = cl;
+    T.cenA[1][p] = cr;
+    T.mask[p] = m;
+    if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cr;      // cenX_R index = xr + 3
+    if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cl;      // cenX_L index = xl
+}
+
+// the border columns of the extended tables: xr in [-3, 2] and xl in [W-3, W+3]
+__global__ void __launch_bounds__(64) k_prep_edges(int H, int W, Tables T)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const int e = threadIdx.x & 15;
+    if (i >= H || e >= 13) return;
+    const uint8_t *Lb = T.u8[0], *Rb = T.u8[1];
+    const int WX = T.WX;
+    if (e < 6) {
+        const int xr = e - 3;
+        if (xr > W - 1) return;                          // narrower than 3 columns
+        const int cc = xr < 0 ? 0 : xr;
+        const unsigned rc = Rb[(size_t)i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                int jj = xr + c;
+                jj = jj < 0 ? 0 : jj;                    // left replicate (:177-178)
+                const bool v = rv && jj < W;
+                const unsigned val = Rb[(size_t)ic * W + (jj < W ? jj : W - 1)];
+                w = (w << 1) | (uint64_t)(v && rc > val);
+            }
+        }
+        T.cenX[0][(size_t)i * WX + e] = w;
+    } else {
+        const int xl = W - 3 + (e - 6);
+        if (xl < 0) return;
+        const int cc = xl > W - 1 ? W - 1 : xl;          // centre clamps to W-1 (:224-225)
+        const unsigned lc = Lb[(size_t)i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                int jj = xl + c;
+                jj = jj >= W ? 0 : jj;                   // neighbour wraps to column 0 (:242-243)
+                const bool v = rv && jj >= 0;
+                const unsigned val = Lb[(size_t)ic * W + (jj < 0 ? 0 : jj)];
+                w = (w << 1) | (uint64_t)(v && lc > val);
+            }
+        }
+        T.cenX[1][(size_t)i * WX + xl] = w;
+    }
 }
 
 template <int C> struct vecf;
@@ -566,14 +600,12 @@ static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
 static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int views, float *dL,
                          float *dR)
 {
-    const int H = h->H, W = h->W, D = h->D, N = H * W;
+    const int H = h->H, W = h->W, D = h->D;
     const bool timed = h->timing;
     hipEvent_t *ev = timed ? h->ev + 3 * (h->n_timed % SMT_TIMING_SLOTS) : nullptr;
     if (timed) (void)hipEventRecord(ev[0], h->stream);
-    hipLaunchKernelGGL(k_to_u8, dim3((N + 255) / 256), dim3(256), 0, h->stream, L, R, N,
-                       h->T.u8[0], h->T.u8[1], h->T.flag);
-    hipLaunchKernelGGL(k_prep, dim3((h->T.WX + 255) / 256, H), dim3(256), 0, h->stream, L, R, H, W,
-                       h->T);
+    hipLaunchKernelGGL(k_prep, dim3((W + PTW - 1) / PTW, H), dim3(PTW), 0, h->stream, L, R, H, W, h->T);
+    hipLaunchKernelGGL(k_prep_edges, dim3((H + 3) / 4), dim3(64), 0, h->stream, H, W, h->T);
     if (timed) (void)hipEventRecord(ev[1], h->stream);
     const int view0 = (views & SMT_VIEW_LEFT) ? 0 : 1;
     const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
