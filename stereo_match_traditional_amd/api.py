@@ -244,6 +244,9 @@ class CrossArmAggregation:
         """0 pipelined walk (default), 1 plain walk, 2 LDS-staged workgroups."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
 
+    def set_strip_width(self, w):
+        check(lib().smt_crossarm_set_strip_width(self._h, int(w)), "smt_crossarm_set_strip_width")
+
     def status(self):
         check(lib().smt_crossarm_status(self._h), "smt_crossarm_status")
 

@@ -199,13 +199,26 @@ __global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__
                                                        int H, int W, int D, const int *__restrict__ armL,
                                                        const int *__restrict__ armR, const int *__restrict__ armT,
                                                        const int *__restrict__ armB, float *__restrict__ disp,
-                                                       int *ub_flag)
+                                                       int *ub_flag, int SW)
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = H * W;
-    const int p = blockIdx.x * (NT / 64) + wv;
-    if (p >= N) return;
+    // XCD-aware pixel order (speed only; any placement is correct): blocks b and b+8 share an XCD
+    // (MI355X_MICROARCH.md), so XCD x = b%8 sweeps the column strips x, x+8, x+16, ... of width SW
+    // row by row.  The pixels in flight on one XCD then cover a few rows of one narrow strip and
+    // their rectangles' union stays inside that XCD's 4 MB L2.
+    int p;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int gpr = SW / (NT / 64);                  // 4-pixel groups per strip row
+        const int gps = gpr * H;                         // groups per strip
+        const int strip = xcd + 8 * (slot / gps);
+        const int g = slot % gps;
+        const int row = g / gpr, col = strip * SW + (g % gpr) * (NT / 64) + wv;
+        if (col >= W || strip * SW >= W) return;
+        p = row * W + col;
+    }
     const int Ll = __builtin_amdgcn_readfirstlane(armL[p]), Rr = __builtin_amdgcn_readfirstlane(armR[p]);
     const int up = __builtin_amdgcn_readfirstlane(armT[p]), dn = __builtin_amdgcn_readfirstlane(armB[p]);
     const int dl = lane * C;
@@ -214,44 +227,70 @@ __global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__
     const int nO = (ORDER == 0) ? (Ll + Rr + 1) : (up + dn + 1);
     const int sI = (ORDER == 0) ? W : 1, sO = (ORDER == 0) ? 1 : W;
     const int total = nI * nO;
-    int idx = p - Ll - up * W;                 // first tap (both orders start at the top-left corner)
-    int inner = 0;
-    const int wrap = sO - nI * sI;             // from the last inner position to the next outer start
+    const int first = p - Ll - up * W;                   // top-left corner (first tap in both orders)
+    const long lastp = (long)p + Rr + (long)dn * W;      // bottom-right corner (last tap)
+    const bool ub = (first < 0) || (lastp >= N);         // flat indices are monotone in both axes
     float acc[C];
 #pragma unroll
     for (int k = 0; k < C; k++) acc[k] = 0.0f;
-    bool ub = false;
-    const float *base = vin + dl;
+    const char *base = (const char *)(vin + dl);         // + tap byte offset (< 2^32: V*4 bytes <= 1.6e9... checked by host)
 
-    for (int n0 = 0; n0 < total; n0 += AU) {
-        float x[AU][C];
-        bool ok[AU];
+    auto ld = [&](unsigned off, float (&x)[C]) {
+        const float *src = (const float *)(base + off);
+        if (FULL) {
+            const vecf<C> v = *reinterpret_cast<const vecf<C> *>(src);
 #pragma unroll
-        for (int u = 0; u < AU; u++) {
-            const bool in_rect = (n0 + u < total);
-            const bool in_plane = (idx >= 0 && idx < N);
-            ok[u] = in_rect && in_plane;
-            ub = ub || (in_rect && !in_plane);
-            const float *src = base + (size_t)(ok[u] ? idx : p) * D;
-            if (FULL) {
-                const vecf<C> v = *reinterpret_cast<const vecf<C> *>(src);
+            for (int k = 0; k < C; k++) x[k] = v.v[k];
+        } else {
 #pragma unroll
-                for (int k = 0; k < C; k++) x[u][k] = v.v[k];
-            } else {
+            for (int k = 0; k < C; k++) x[k] = (dl + k < D) ? src[k] : 0.0f;
+        }
+    };
+
+    if (!ub) {
+        // fast path: every tap is inside the plane.  Lanes compute the byte offsets of the next 64
+        // taps in parallel (one division per 64 taps); the tap loop is readlane + load + adds.
+        const float rI = 1.0f / (float)nI;
+        for (int n0 = 0; n0 < total; n0 += 64) {
+            const int n = n0 + lane;
+            int o = (int)((float)n * rI);                // n < 4761, nI <= 69: off by at most one, fixed below
+            int t = n - o * nI;
+            if (t < 0) { o--; t += nI; }
+            if (t >= nI) { o++; t -= nI; }
+            const unsigned offs = (unsigned)(first + o * sO + t * sI) * (unsigned)(D * 4);
+            const int cnt = min(64, total - n0);         // scalar
+            int u = 0;
+            for (; u + AU <= cnt; u += AU) {
+                float x[AU][C];
 #pragma unroll
-                for (int k = 0; k < C; k++) x[u][k] = (dl + k < D) ? src[k] : 0.0f;
+                for (int k = 0; k < AU; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u + k), x[k]);
+#pragma unroll
+                for (int k = 0; k < AU; k++) {
+#pragma unroll
+                    for (int c = 0; c < C; c++) acc[c] = acc[c] + x[k][c];
+                }
             }
-            // advance the walk (scalar)
-            inner++;
-            idx += sI;
+            for (; u < cnt; u++) {
+                float x[C];
+                ld((unsigned)__builtin_amdgcn_readlane((int)offs, u), x);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = acc[c] + x[c];
+            }
+        }
+    } else {
+        // reference UB (rectangle leaves the plane): out-of-plane taps contribute nothing
+        int idx = first, inner = 0;
+        const int wrap = sO - nI * sI;
+        for (int n = 0; n < total; n++) {
+            if (idx >= 0 && idx < N) {
+                float x[C];
+                ld((unsigned)idx * (unsigned)(D * 4), x);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = acc[c] + x[c];
+            }
+            inner++; idx += sI;
             if (inner == nI) { inner = 0; idx += wrap; }
         }
-#pragma unroll
-        for (int u = 0; u < AU; u++)
-            if (ok[u]) {
-#pragma unroll
-                for (int k = 0; k < C; k++) acc[k] = acc[k] + x[u][k];
-            }
     }
     const float cnt = (float)total;
     float best = INFINITY; int bk = 0;
@@ -390,6 +429,128 @@ __global__ void __launch_bounds__(ANT) k_aggregate_lds(const float *__restrict__
     }
 }
 
+// ---- LDS-DMA ring aggregation ---------------------------------------------------------------
+// Same decomposition as k_aggregate_lds (16 adjacent pixels per workgroup, union rectangle walked
+// in the reference's order, segments of up to DRCH inner positions), but segments are streamed into
+// a ring of NS LDS slots by `global_load_lds_dwordx4` (no VGPR staging), NS-1 segments ahead of
+// the adds.  Protocol per segment s:
+//   wave (s mod 16), which alone issued segment s: s_waitcnt vmcnt(0)   (it has issued nothing since)
+//   all waves: lgkmcnt(0) (their reads of segment s-1 are done) ; s_barrier
+//   wave ((s+NS-1) mod 16): issue segment s+NS-1 into the slot segment s-1 just vacated
+//   every wave whose rectangle contains the segment: in-order adds from the slot
+// Out-of-plane lines (reference UB) are not fetched; the flag is raised and the result is
+// unspecified for such inputs.
+constexpr int DRCH = 16;
+
+template <int C, int ORDER>
+__global__ void __launch_bounds__(ANT) k_aggregate_dma(const float *__restrict__ vin, float *__restrict__ vout,
+                                                       int H, int W, int D, int NS, const int *__restrict__ armL,
+                                                       const int *__restrict__ armR, const int *__restrict__ armT,
+                                                       const int *__restrict__ armB, float *__restrict__ disp,
+                                                       int *ub_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_ring[];     // [NS][DRCH][D]
+    __shared__ int s_rng[APB][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = H * W;
+    const int p0 = blockIdx.x * APB;
+    const int p = p0 + w;
+    const bool live = p < N;
+
+    int oa = 1, ob = 0, ia = 1, ib = 0, cnt = 1;
+    if (live) {
+        const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
+        cnt = (Ll + Rr + 1) * (up + dn + 1);
+        if (ORDER == 0) { oa = w - Ll; ob = w + Rr; ia = -up; ib = dn; }
+        else            { oa = -up;    ob = dn;     ia = w - Ll; ib = w + Rr; }
+    }
+    oa = __builtin_amdgcn_readfirstlane(oa); ob = __builtin_amdgcn_readfirstlane(ob);
+    ia = __builtin_amdgcn_readfirstlane(ia); ib = __builtin_amdgcn_readfirstlane(ib);
+    if (lane == 0) { s_rng[w][0] = oa; s_rng[w][1] = ob; s_rng[w][2] = ia; s_rng[w][3] = ib; }
+    __syncthreads();
+    int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
+#pragma unroll
+    for (int k = 0; k < APB; k++) {
+        if (s_rng[k][0] <= s_rng[k][1]) {
+            omin = min(omin, s_rng[k][0]); omax = max(omax, s_rng[k][1]);
+            imin = min(imin, s_rng[k][2]); imax = max(imax, s_rng[k][3]);
+        }
+    }
+    omin = __builtin_amdgcn_readfirstlane(omin); omax = __builtin_amdgcn_readfirstlane(omax);
+    imin = __builtin_amdgcn_readfirstlane(imin); imax = __builtin_amdgcn_readfirstlane(imax);
+    const long so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
+    const int nch = (imax - imin + 1 + DRCH - 1) / DRCH;
+    const int nseg = (omax >= omin) ? (omax - omin + 1) * nch : 0;
+    const int RB = D * 4;                                // bytes per line
+    const int slot_floats = DRCH * D;
+    const int nq = (DRCH * RB + 1023) / 1024;            // DMA instructions per full segment
+    const int dl = lane * C;
+
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.0f;
+    const bool ub = live && ((long)p0 + oa * so + (long)ia * si < 0 || (long)p0 + ob * so + (long)ib * si >= N);
+
+    auto issue = [&](int seg) {
+        if (w != seg % APB) return;                      // scalar branch
+        const int o = omin + seg / nch, n0 = imin + (seg % nch) * DRCH;
+        float *slot = s_ring + (size_t)(seg % NS) * slot_floats;
+        const int rows = min(DRCH, imax - n0 + 1);
+        const int bytes = rows * RB;
+        for (int q = 0; q < nq; q++) {
+            const int e = q * 1024 + lane * 16;          // byte offset inside the slot
+            if (q * 1024 >= bytes) break;
+            const int row = e / RB, byte = e - row * RB;
+            const long idx = (long)p0 + o * so + (long)(n0 + row) * si;
+            if (e < bytes && idx >= 0 && idx < N) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(vin + idx * D + (byte >> 2)),
+                    (__attribute__((address_space(3))) void *)(slot + q * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    for (int s = 0; s < NS - 1 && s < nseg; s++) issue(s);
+    for (int seg = 0; seg < nseg; seg++) {
+        if (w == seg % APB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (seg + NS - 1 < nseg) issue(seg + NS - 1);
+        const int o = omin + seg / nch, n0 = imin + (seg % nch) * DRCH;
+        if (o >= oa && o <= ob) {
+            const int a = max(n0, ia), b = min(n0 + DRCH - 1, ib);
+            const float *src = s_ring + (size_t)(seg % NS) * slot_floats + dl;
+            for (int n = a; n <= b; n++) {
+                const float *r = src + (n - n0) * D;
+#pragma unroll
+                for (int k = 0; k < C; k++)
+                    if (dl + k < D) acc[k] = acc[k] + r[k];
+            }
+        }
+    }
+
+    if (__syncthreads_or(ub) && tid == 0) atomicOr(ub_flag, 1);
+    if (!live) return;
+    const float fc = (float)cnt;
+    float best = INFINITY; int bk = 0;
+    float *dst = vout + (size_t)p * D + dl;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        acc[k] = acc[k] / fc;
+        if (dl + k < D) {
+            dst[k] = acc[k];
+            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
+        }
+    }
+    if (disp) {
+        if (dl >= D) best = INFINITY;
+        const int wd = wave_argmin_first(best, dl + bk);
+        if (lane == 0) disp[p] = (float)wd;
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_cblsm_ad(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R,
                                                  int H, int W, int D, int view, float *__restrict__ vol)
 {
@@ -421,6 +582,7 @@ struct smt_crossarm {
     int *flip;     // 4 flip indices + 1 UB flag
     bool have_arms;
     int variant;         // aggregation kernel variant (test / tuning hook)
+    int strip_w;         // column-strip width of the XCD-aware pixel order (variant 0)
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -440,7 +602,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
-    h->H = H; h->W = W; h->D = D;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 64;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
@@ -523,16 +685,46 @@ static void launch_agg_lds(smt_crossarm *h, const float *vin, float *vout, float
 }
 
 template <int ORDER>
-static void launch_agg_pipe(smt_crossarm *h, const float *vin, float *vout, float *disp)
+static int launch_agg_dma(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
     const int N = h->H * h->W;
-    dim3 grid((N + 3) / 4);
+    dim3 grid((N + APB - 1) / APB);
+    const int C = (h->D + 63) / 64;
+    const int slot = DRCH * h->D * 4;
+    int NS = 65536 / slot;
+    NS = NS < 3 ? 3 : (NS > 8 ? 8 : NS);
+    const size_t shm = (size_t)NS * slot;
+    int *ub = h->flip + 4;
+#define SMT_AGGD(CC)                                                                                       \
+    do {                                                                                                   \
+        auto kfn = k_aggregate_dma<CC, ORDER>;                                                             \
+        SMT_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL(kfn, grid, dim3(ANT), shm, h->stream, vin, vout, h->H, h->W, h->D, NS, h->arm[0],  \
+                           h->arm[1], h->arm[2], h->arm[3], disp, ub);                                     \
+    } while (0)
+    switch (C) {
+    case 1: SMT_AGGD(1); break;
+    case 2: SMT_AGGD(2); break;
+    case 3: SMT_AGGD(3); break;
+    default: SMT_AGGD(4); break;
+    }
+#undef SMT_AGGD
+    return SMT_OK;
+}
+
+template <int ORDER>
+static void launch_agg_pipe(smt_crossarm *h, const float *vin, float *vout, float *disp)
+{
+    const int SW = h->strip_w;                           // strip width (multiple of 4)
+    const int nstrips = (h->W + SW - 1) / SW;
+    const int per_xcd = (nstrips + 7) / 8;               // strips per XCD
+    dim3 grid((unsigned)(8 * per_xcd * (SW / 4) * h->H));
     const int C = (h->D + 63) / 64;
     const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
 #define SMT_AGGP(CC, FF)                                                                                  \
     hipLaunchKernelGGL((k_aggregate_pipe<CC, ORDER, FF>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
-                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub)
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW)
     switch (C * 2 + (full ? 1 : 0)) {
     case 2: SMT_AGGP(1, false); break;
     case 3: SMT_AGGP(1, true); break;
@@ -569,10 +761,16 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 0 = pipelined direct (default), 1 = simple direct, 2 = LDS-staged (D % 4 == 0)
+    // variant: 0 = pipelined direct (default), 1 = simple direct, 2 = LDS-staged, 3 = LDS-DMA ring
+    // (2 and 3 need D % 4 == 0 and fall back to 0 otherwise)
     int variant = h->variant;
-    if (variant == 2 && (h->D % 4)) variant = 0;
-    if (variant == 2) { if (order == 0) launch_agg_lds<0>(h, vin, vout, disp); else launch_agg_lds<1>(h, vin, vout, disp); }
+    if (variant >= 2 && (h->D % 4)) variant = 0;
+    // variant 0 addresses taps with 32-bit byte offsets
+    if (variant == 0 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
+    if (variant == 3) {
+        int rc = (order == 0) ? launch_agg_dma<0>(h, vin, vout, disp) : launch_agg_dma<1>(h, vin, vout, disp);
+        if (rc != SMT_OK) return rc;
+    } else if (variant == 2) { if (order == 0) launch_agg_lds<0>(h, vin, vout, disp); else launch_agg_lds<1>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
@@ -581,8 +779,15 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 2) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 3) return SMT_ERR_ARG;
     h->variant = variant;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_set_strip_width(smt_crossarm *h, int w)
+{
+    if (!h || w < 4 || (w & 3)) return SMT_ERR_ARG;
+    h->strip_w = w;
     return SMT_OK;
 }
 

@@ -95,7 +95,7 @@ AGG_CASES = [(72, 160, 16, "synth", 3), (64, 150, 64, "smooth", 5), (72, 160, 10
 AGG_CASES += [(70, 155, 60, "smooth", 12), (66, 149, 7, "synth", 13)]   # W % 16 != 0, D % 4 != 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("H,W,D,kind,seed", AGG_CASES)
 @pytest.mark.parametrize("order", [0, 1])
 def test_aggregation(smt, O, H, W, D, kind, seed, order, variant):
