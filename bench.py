@@ -81,8 +81,9 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # torch.distributed.run
+    if world > 1 or launched:
+        dist.init_process_group("nccl", device_id=dev)                   # RCCL on ROCm
 
     import stereo_match_traditional_amd as smt
     from stereo_match_traditional_amd import synth
@@ -102,7 +103,7 @@ def main():
         adc.ComputeBatch(Lb, Rb, dl, dr)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,7 +114,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if dist.is_initialized():
         # config 5's only exchange: gather the disparity maps, all-reduce a checksum (shard.py)
         from stereo_match_traditional_amd import shard
         shard.gather_disparities(dl, world * P)
@@ -125,7 +126,7 @@ def main():
     adc.status()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -163,7 +164,7 @@ def main():
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(H, W, D, seed, args.cpu_rows)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -177,8 +177,9 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising */
 /* Test / tuning hook: which aggregation kernel runs.  0 = pipelined one-wave-per-pixel walk
- * (default), 1 = plain one-wave-per-pixel walk, 2 = LDS-staged 16-pixel workgroups, 3 = the same fed by an LDS-DMA
- * ring (2 and 3 need D % 4 == 0 and fall back to 0 otherwise).  All produce identical bits. */
+ * (default), 1 = plain one-wave-per-pixel walk, 2 = one wave per 8 adjacent pixels sharing line
+ * segments through wave-private LDS (D % 64 == 0, else 0; pays only when neighbouring arms are
+ * similar).  All produce identical bits. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps in variant 0. */
 int smt_crossarm_set_strip_width(smt_crossarm *h, int width);

@@ -311,243 +311,166 @@ __global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__
     }
 }
 
-// ---- LDS-staged aggregation ---------------------------------------------------------------
-// APB adjacent pixels per workgroup, one wave each (lanes = disparities, C per lane).  The
-// rectangles of adjacent pixels overlap almost completely, so the workgroup walks the union
-// of their rectangles in the reference's outer/inner order and stages every line segment
-// (up to RCH consecutive inner positions of one outer position, D floats each) ONCE in LDS;
-// each wave then adds the part of the segment that lies inside its own rectangle, in order.
-// Addresses are flat (p0 + o*so + n*si), which reproduces the reference's wrap across row
-// ends ((i+top)*col + j + left, CrossArm.cpp:92) without special cases.
-//   ORDER 0 (AggregationVertical): outer = column offset (stride 1), inner = row (stride W)
-//   ORDER 1 (costAggregationV5)  : outer = row (stride W),    inner = column (stride 1)
-constexpr int APB = 16;           // pixels (waves) per workgroup
-constexpr int RCH = 16;           // staged inner positions per segment
-constexpr int ANT = APB * 64;
+// ---- wave-private LDS aggregation (D == 64*C) -------------------------------------------------
+// One wave owns WP adjacent pixels.  Their rectangles overlap almost entirely, so the wave walks
+// the UNION of the WP rectangles in the reference's outer/inner order in segments of WR inner
+// positions, streams each segment once into a wave-private LDS ring with global_load_lds (no
+// VGPR staging, no workgroup barrier -- the only synchronisation is the wave's own counted
+// vmcnt), and every pixel whose rectangle contains the segment adds its part from LDS, in
+// order.  Global loads drop by the overlap factor (~5x for typical arms); the adds read LDS.
+// Rectangles that leave the plane (reference UB) take the per-pixel slow path.
+constexpr int WP = 8;             // pixels per wave
+constexpr int WR = 8;             // inner positions per segment
+constexpr int WNS = 3;            // ring slots per wave
 
 template <int C, int ORDER>
-__global__ void __launch_bounds__(ANT) k_aggregate_lds(const float *__restrict__ vin, float *__restrict__ vout,
-                                                       int H, int W, int D, const int *__restrict__ armL,
+__global__ void __launch_bounds__(NT) k_aggregate_wave(const float *__restrict__ vin, float *__restrict__ vout,
+                                                       int H, int W, const int *__restrict__ armL,
                                                        const int *__restrict__ armR, const int *__restrict__ armT,
                                                        const int *__restrict__ armB, float *__restrict__ disp,
-                                                       int *ub_flag)
+                                                       int *ub_flag, int SW)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_buf[];      // [2][RCH][D]
-    __shared__ int s_rng[APB][4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int D = 64 * C;
+    constexpr int RB = D * 4;                            // bytes per line
+    constexpr int SLOT = WR * D;                         // floats per slot
+    constexpr int NQ = (WR * RB) / 1024;                 // DMA instructions per segment (= 2*C)
+    extern __shared__ __attribute__((aligned(16))) float s_w[];        // [waves][WNS][WR][D]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *ring = s_w + (size_t)wv * WNS * SLOT;
     const int N = H * W;
-    const int p0 = blockIdx.x * APB;
-    const int p = p0 + w;
-    const bool live = p < N;
 
-    // this wave's rectangle as [oa,ob] x [ia,ib] relative to p0
-    int oa = 1, ob = 0, ia = 1, ib = 0, cnt = 1;
-    if (live) {
-        const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
-        cnt = (Ll + Rr + 1) * (up + dn + 1);
-        if (ORDER == 0) { oa = w - Ll; ob = w + Rr; ia = -up; ib = dn; }
-        else            { oa = -up;    ob = dn;     ia = w - Ll; ib = w + Rr; }
+    // XCD-aware order as in k_aggregate_pipe; a wave takes WP consecutive pixels of a strip row
+    int p0, nlive;
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int gpr = SW / (WP * (NT / 64));           // blocks per strip row
+        const int gps = gpr * H;
+        const int strip = xcd + 8 * (slot / gps);
+        const int g = slot % gps;
+        const int row = g / gpr, col = strip * SW + ((g % gpr) * (NT / 64) + wv) * WP;
+        if (col >= W || strip * SW >= W) return;
+        p0 = row * W + col;
+        nlive = min(WP, W - col);
     }
-    if (lane == 0) { s_rng[w][0] = oa; s_rng[w][1] = ob; s_rng[w][2] = ia; s_rng[w][3] = ib; }
-    __syncthreads();
+    // rectangles relative to p0: pixel q covers outer [oa,ob] x inner [ia,ib]
+    int oa[WP], ob[WP], ia[WP], ib[WP], cnt[WP];
     int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
+    bool ub = false;
 #pragma unroll
-    for (int k = 0; k < APB; k++) {
-        if (s_rng[k][0] <= s_rng[k][1]) {
-            omin = min(omin, s_rng[k][0]); omax = max(omax, s_rng[k][1]);
-            imin = min(imin, s_rng[k][2]); imax = max(imax, s_rng[k][3]);
+    for (int q = 0; q < WP; q++) {
+        oa[q] = 1; ob[q] = 0; ia[q] = 1; ib[q] = 0; cnt[q] = 1;
+        if (q < nlive) {
+            const int p = p0 + q;
+            const int Ll = __builtin_amdgcn_readfirstlane(armL[p]), Rr = __builtin_amdgcn_readfirstlane(armR[p]);
+            const int up = __builtin_amdgcn_readfirstlane(armT[p]), dn = __builtin_amdgcn_readfirstlane(armB[p]);
+            cnt[q] = (Ll + Rr + 1) * (up + dn + 1);
+            if (ORDER == 0) { oa[q] = q - Ll; ob[q] = q + Rr; ia[q] = -up; ib[q] = dn; }
+            else            { oa[q] = -up;    ob[q] = dn;     ia[q] = q - Ll; ib[q] = q + Rr; }
+            omin = min(omin, oa[q]); omax = max(omax, ob[q]);
+            imin = min(imin, ia[q]); imax = max(imax, ib[q]);
+            ub = ub || (p - Ll - up * W < 0) || ((long)p + Rr + (long)dn * W >= N);
         }
     }
-    const long so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
-    const int nin = imax - imin + 1;
-    const int nch = (nin + RCH - 1) / RCH;               // chunks per outer position
-    const int nseg = (omax - omin + 1) * nch;
-    const int D4 = D >> 2;                               // D % 4 == 0 on this path
+    const int so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
     const int dl = lane * C;
-
-    float acc[C];
+    float acc[WP][C];
 #pragma unroll
-    for (int k = 0; k < C; k++) acc[k] = 0.0f;
-    // flat indices grow with both o and n: the rectangle leaves the plane iff a corner does
-    const bool ub = live && ((long)p0 + oa * so + (long)ia * si < 0 || (long)p0 + ob * so + (long)ib * si >= N);
+    for (int q = 0; q < WP; q++)
+#pragma unroll
+        for (int k = 0; k < C; k++) acc[q][k] = 0.0f;
 
-    // each thread stages at most one float4 per segment (RCH * D4 <= ANT for D <= 256)
-    const int sl = tid / D4, sq = tid - sl * D4;         // staged line, float4 within the line
-    float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int seg) {
-        const int o = omin + seg / nch, n0 = imin + (seg % nch) * RCH;
-        stage = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sl < RCH && n0 + sl <= imax) {
-            const long idx = (long)p0 + o * so + (long)(n0 + sl) * si;
-            // lines of the union box that lie outside the plane are staged as zeros; whether a
-            // rectangle really uses one is decided per wave below
-            if (idx >= 0 && idx < N) stage = *reinterpret_cast<const float4 *>(vin + idx * D + 4 * sq);
+    if (!ub) {
+        const int nch = (imax - imin + 1 + WR - 1) / WR;
+        const int nseg = (omax - omin + 1) * nch;
+        // per-lane position inside a segment for each of the NQ DMA instructions
+        int lrow[NQ], lbyte[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+            const int e = k * 1024 + lane * 16;
+            lrow[k] = e / RB;
+            lbyte[k] = e - lrow[k] * RB;
         }
-    };
-    auto commit = [&](int seg) {
-        if (sl < RCH) *reinterpret_cast<float4 *>(s_buf + (size_t)(seg & 1) * RCH * D + sl * D + 4 * sq) = stage;
-    };
-
-    if (nseg > 0) { fetch(0); commit(0); }
-    __syncthreads();
-    for (int seg = 0; seg < nseg; seg++) {
-        if (seg + 1 < nseg) fetch(seg + 1);              // global loads in flight during the adds
-        const int o = omin + seg / nch, n0 = imin + (seg % nch) * RCH;
-        if (o >= oa && o <= ob) {
-            const int a = max(n0, ia), b = min(n0 + RCH - 1, ib);
-            const float *src = s_buf + (size_t)(seg & 1) * RCH * D + dl;
-            for (int n = a; n <= b; n++) {
-                const float *r = src + (n - n0) * D;
+        auto issue = [&](int seg) {
+            const int o = omin + seg / nch, n0 = imin + (seg % nch) * WR;
+            const int rows = min(WR, imax - n0 + 1);     // lines really needed; the rest re-read line 0
+            const int idx0 = p0 + o * so + n0 * si;
+            float *slot = ring + (seg % WNS) * SLOT;
 #pragma unroll
-                for (int k = 0; k < C; k++)
-                    if (dl + k < D) acc[k] = acc[k] + r[k];
-            }
-        }
-        if (seg + 1 < nseg) commit(seg + 1);
-        __syncthreads();
-    }
-
-    if (__syncthreads_or(ub) && tid == 0) atomicOr(ub_flag, 1);
-    if (!live) return;
-    const float fc = (float)cnt;
-    float best = INFINITY; int bk = 0;
-    float *dst = vout + (size_t)p * D + dl;
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-        acc[k] = acc[k] / fc;
-        if (dl + k < D) {
-            dst[k] = acc[k];
-            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
-        }
-    }
-    if (disp) {
-        if (dl >= D) best = INFINITY;
-        const int wd = wave_argmin_first(best, dl + bk);
-        if (lane == 0) disp[p] = (float)wd;
-    }
-}
-
-// ---- LDS-DMA ring aggregation ---------------------------------------------------------------
-// Same decomposition as k_aggregate_lds (16 adjacent pixels per workgroup, union rectangle walked
-// in the reference's order, segments of up to DRCH inner positions), but segments are streamed into
-// a ring of NS LDS slots by `global_load_lds_dwordx4` (no VGPR staging), NS-1 segments ahead of
-// the adds.  Protocol per segment s:
-//   wave (s mod 16), which alone issued segment s: s_waitcnt vmcnt(0)   (it has issued nothing since)
-//   all waves: lgkmcnt(0) (their reads of segment s-1 are done) ; s_barrier
-//   wave ((s+NS-1) mod 16): issue segment s+NS-1 into the slot segment s-1 just vacated
-//   every wave whose rectangle contains the segment: in-order adds from the slot
-// Out-of-plane lines (reference UB) are not fetched; the flag is raised and the result is
-// unspecified for such inputs.
-constexpr int DRCH = 16;
-
-template <int C, int ORDER>
-__global__ void __launch_bounds__(ANT) k_aggregate_dma(const float *__restrict__ vin, float *__restrict__ vout,
-                                                       int H, int W, int D, int NS, const int *__restrict__ armL,
-                                                       const int *__restrict__ armR, const int *__restrict__ armT,
-                                                       const int *__restrict__ armB, float *__restrict__ disp,
-                                                       int *ub_flag)
-{
-    extern __shared__ __attribute__((aligned(16))) float s_ring[];     // [NS][DRCH][D]
-    __shared__ int s_rng[APB][4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = H * W;
-    const int p0 = blockIdx.x * APB;
-    const int p = p0 + w;
-    const bool live = p < N;
-
-    int oa = 1, ob = 0, ia = 1, ib = 0, cnt = 1;
-    if (live) {
-        const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
-        cnt = (Ll + Rr + 1) * (up + dn + 1);
-        if (ORDER == 0) { oa = w - Ll; ob = w + Rr; ia = -up; ib = dn; }
-        else            { oa = -up;    ob = dn;     ia = w - Ll; ib = w + Rr; }
-    }
-    oa = __builtin_amdgcn_readfirstlane(oa); ob = __builtin_amdgcn_readfirstlane(ob);
-    ia = __builtin_amdgcn_readfirstlane(ia); ib = __builtin_amdgcn_readfirstlane(ib);
-    if (lane == 0) { s_rng[w][0] = oa; s_rng[w][1] = ob; s_rng[w][2] = ia; s_rng[w][3] = ib; }
-    __syncthreads();
-    int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
-#pragma unroll
-    for (int k = 0; k < APB; k++) {
-        if (s_rng[k][0] <= s_rng[k][1]) {
-            omin = min(omin, s_rng[k][0]); omax = max(omax, s_rng[k][1]);
-            imin = min(imin, s_rng[k][2]); imax = max(imax, s_rng[k][3]);
-        }
-    }
-    omin = __builtin_amdgcn_readfirstlane(omin); omax = __builtin_amdgcn_readfirstlane(omax);
-    imin = __builtin_amdgcn_readfirstlane(imin); imax = __builtin_amdgcn_readfirstlane(imax);
-    const long so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
-    const int nch = (imax - imin + 1 + DRCH - 1) / DRCH;
-    const int nseg = (omax >= omin) ? (omax - omin + 1) * nch : 0;
-    const int RB = D * 4;                                // bytes per line
-    const int slot_floats = DRCH * D;
-    const int nq = (DRCH * RB + 1023) / 1024;            // DMA instructions per full segment
-    const int dl = lane * C;
-
-    float acc[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) acc[k] = 0.0f;
-    const bool ub = live && ((long)p0 + oa * so + (long)ia * si < 0 || (long)p0 + ob * so + (long)ib * si >= N);
-
-    auto issue = [&](int seg) {
-        if (w != seg % APB) return;                      // scalar branch
-        const int o = omin + seg / nch, n0 = imin + (seg % nch) * DRCH;
-        float *slot = s_ring + (size_t)(seg % NS) * slot_floats;
-        const int rows = min(DRCH, imax - n0 + 1);
-        const int bytes = rows * RB;
-        for (int q = 0; q < nq; q++) {
-            const int e = q * 1024 + lane * 16;          // byte offset inside the slot
-            if (q * 1024 >= bytes) break;
-            const int row = e / RB, byte = e - row * RB;
-            const long idx = (long)p0 + o * so + (long)(n0 + row) * si;
-            if (e < bytes && idx >= 0 && idx < N) {
+            for (int k = 0; k < NQ; k++) {
+                const int r = lrow[k] < rows ? lrow[k] : 0;
+                // union-box positions that belong to no rectangle may lie outside the plane: clamp
+                // the source line (its data is never added)
+                int idx = idx0 + r * si;
+                idx = idx < 0 ? 0 : (idx > N - 1 ? N - 1 : idx);
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(vin + idx * D + (byte >> 2)),
-                    (__attribute__((address_space(3))) void *)(slot + q * 256), 16, 0, 0);
+                    (const __attribute__((address_space(1))) void *)((const char *)vin + (size_t)idx * RB + lbyte[k]),
+                    (__attribute__((address_space(3))) void *)(slot + k * 256), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < WNS - 1; s++)
+            if (s < nseg) issue(s);
+        for (int seg = 0; seg < nseg; seg++) {
+            // the slot segment seg-1 used is free once its reads have returned
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (seg + WNS - 1 < nseg) {
+                issue(seg + WNS - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * (WNS - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const int o = omin + seg / nch, n0 = imin + (seg % nch) * WR;
+            const float *src = ring + (seg % WNS) * SLOT + dl;
+#pragma unroll
+            for (int q = 0; q < WP; q++) {
+                if (o >= oa[q] && o <= ob[q]) {
+                    const int a = max(n0, ia[q]) - n0, b = min(n0 + WR - 1, ib[q]) - n0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++) {
+                        if (r >= a && r <= b) {
+#pragma unroll
+                            for (int k = 0; k < C; k++) acc[q][k] = acc[q][k] + src[r * D + k];
+                        }
+                    }
+                }
             }
         }
-    };
-
-    for (int s = 0; s < NS - 1 && s < nseg; s++) issue(s);
-    for (int seg = 0; seg < nseg; seg++) {
-        if (w == seg % APB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (seg + NS - 1 < nseg) issue(seg + NS - 1);
-        const int o = omin + seg / nch, n0 = imin + (seg % nch) * DRCH;
-        if (o >= oa && o <= ob) {
-            const int a = max(n0, ia), b = min(n0 + DRCH - 1, ib);
-            const float *src = s_ring + (size_t)(seg % NS) * slot_floats + dl;
-            for (int n = a; n <= b; n++) {
-                const float *r = src + (n - n0) * D;
+    } else {
+        // reference UB: per-pixel walk, out-of-plane taps contribute nothing
 #pragma unroll
-                for (int k = 0; k < C; k++)
-                    if (dl + k < D) acc[k] = acc[k] + r[k];
-            }
+        for (int q = 0; q < WP; q++) {
+            if (q >= nlive) continue;
+            const int nO = ob[q] - oa[q] + 1, nI = ib[q] - ia[q] + 1;
+            for (int o = 0; o < nO; o++)
+                for (int n = 0; n < nI; n++) {
+                    const long idx = (long)p0 + (long)(oa[q] + o) * so + (long)(ia[q] + n) * si;
+                    if (idx >= 0 && idx < N) {
+                        const vecf<C> v = *reinterpret_cast<const vecf<C> *>(vin + idx * D + dl);
+#pragma unroll
+                        for (int k = 0; k < C; k++) acc[q][k] = acc[q][k] + v.v[k];
+                    }
+                }
         }
+        if (lane == 0) atomicOr(ub_flag, 1);
     }
 
-    if (__syncthreads_or(ub) && tid == 0) atomicOr(ub_flag, 1);
-    if (!live) return;
-    const float fc = (float)cnt;
-    float best = INFINITY; int bk = 0;
-    float *dst = vout + (size_t)p * D + dl;
 #pragma unroll
-    for (int k = 0; k < C; k++) {
-        acc[k] = acc[k] / fc;
-        if (dl + k < D) {
-            dst[k] = acc[k];
-            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
+    for (int q = 0; q < WP; q++) {
+        if (q >= nlive) continue;
+        const float fc = (float)cnt[q];
+        vecf<C> o;
+        float best = 0.0f; int bk = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            o.v[k] = acc[q][k] / fc;
+            if (k == 0 || best > o.v[k]) { best = o.v[k]; bk = k; }
         }
-    }
-    if (disp) {
-        if (dl >= D) best = INFINITY;
-        const int wd = wave_argmin_first(best, dl + bk);
-        if (lane == 0) disp[p] = (float)wd;
+        *reinterpret_cast<vecf<C> *>(vout + (size_t)(p0 + q) * D + dl) = o;
+        if (disp) {
+            const int wd = wave_argmin_first(best, dl + bk);
+            if (lane == 0) disp[p0 + q] = (float)wd;
+        }
     }
 }
 
@@ -665,50 +588,31 @@ SMT_API int smt_crossarm_arm_maps(smt_crossarm *h, int **l, int **r, int **t, in
 }
 
 template <int ORDER>
-static void launch_agg_lds(smt_crossarm *h, const float *vin, float *vout, float *disp)
+static int launch_agg_wave(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
-    const int N = h->H * h->W;
-    dim3 grid((N + APB - 1) / APB);
-    const int C = (h->D + 63) / 64;
-    const size_t shm = (size_t)2 * RCH * h->D * 4;
+    const int C = h->D / 64;
+    int SW = h->strip_w;
+    const int bw = WP * (NT / 64);                       // pixels per block along a strip row
+    SW = ((SW + bw - 1) / bw) * bw;
+    const int nstrips = (h->W + SW - 1) / SW;
+    const int per_xcd = (nstrips + 7) / 8;
+    dim3 grid((unsigned)(8 * per_xcd * (SW / bw) * h->H));
+    const size_t shm = (size_t)(NT / 64) * WNS * WR * h->D * 4;
     int *ub = h->flip + 4;
-#define SMT_AGGL(CC)                                                                                     \
-    hipLaunchKernelGGL((k_aggregate_lds<CC, ORDER>), grid, dim3(ANT), shm, h->stream, vin, vout, h->H, h->W, \
-                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub)
-    switch (C) {
-    case 1: SMT_AGGL(1); break;
-    case 2: SMT_AGGL(2); break;
-    case 3: SMT_AGGL(3); break;
-    default: SMT_AGGL(4); break;
-    }
-#undef SMT_AGGL
-}
-
-template <int ORDER>
-static int launch_agg_dma(smt_crossarm *h, const float *vin, float *vout, float *disp)
-{
-    const int N = h->H * h->W;
-    dim3 grid((N + APB - 1) / APB);
-    const int C = (h->D + 63) / 64;
-    const int slot = DRCH * h->D * 4;
-    int NS = 65536 / slot;
-    NS = NS < 3 ? 3 : (NS > 8 ? 8 : NS);
-    const size_t shm = (size_t)NS * slot;
-    int *ub = h->flip + 4;
-#define SMT_AGGD(CC)                                                                                       \
+#define SMT_AGGW(CC)                                                                                       \
     do {                                                                                                   \
-        auto kfn = k_aggregate_dma<CC, ORDER>;                                                             \
+        auto kfn = k_aggregate_wave<CC, ORDER>;                                                            \
         SMT_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL(kfn, grid, dim3(ANT), shm, h->stream, vin, vout, h->H, h->W, h->D, NS, h->arm[0],  \
-                           h->arm[1], h->arm[2], h->arm[3], disp, ub);                                     \
+        hipLaunchKernelGGL(kfn, grid, dim3(NT), shm, h->stream, vin, vout, h->H, h->W, h->arm[0], h->arm[1],  \
+                           h->arm[2], h->arm[3], disp, ub, SW);                                            \
     } while (0)
     switch (C) {
-    case 1: SMT_AGGD(1); break;
-    case 2: SMT_AGGD(2); break;
-    case 3: SMT_AGGD(3); break;
-    default: SMT_AGGD(4); break;
+    case 1: SMT_AGGW(1); break;
+    case 2: SMT_AGGW(2); break;
+    case 3: SMT_AGGW(3); break;
+    default: SMT_AGGW(4); break;
     }
-#undef SMT_AGGD
+#undef SMT_AGGW
     return SMT_OK;
 }
 
@@ -761,17 +665,16 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 0 = pipelined direct (default), 1 = simple direct, 2 = LDS-staged, 3 = LDS-DMA ring
-    // (2 and 3 need D % 4 == 0 and fall back to 0 otherwise)
+    // variant: 0 = pipelined walk (default), 1 = plain walk (any size, also the UB-safe reference
+    // form), 2 = wave-private LDS sharing (needs D % 64 == 0, else 0)
     int variant = h->variant;
-    if (variant >= 2 && (h->D % 4)) variant = 0;
+    if (variant == 2 && (h->D % 64)) variant = 0;
     // variant 0 addresses taps with 32-bit byte offsets
     if (variant == 0 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
-    if (variant == 3) {
-        int rc = (order == 0) ? launch_agg_dma<0>(h, vin, vout, disp) : launch_agg_dma<1>(h, vin, vout, disp);
+    if (variant == 2) {
+        int rc = (order == 0) ? launch_agg_wave<0>(h, vin, vout, disp) : launch_agg_wave<1>(h, vin, vout, disp);
         if (rc != SMT_OK) return rc;
-    } else if (variant == 2) { if (order == 0) launch_agg_lds<0>(h, vin, vout, disp); else launch_agg_lds<1>(h, vin, vout, disp); }
-    else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
+    } else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -779,7 +682,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 3) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 2) return SMT_ERR_ARG;
     h->variant = variant;
     return SMT_OK;
 }

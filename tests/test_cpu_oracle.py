@@ -103,3 +103,48 @@ def test_lrcheck_order_dependence_is_modelled(O):
     dR[0, 3] = -1
     ref, cls, no, nm = O.lrcheck(dL, dR, 0)
     assert cls[0, 6] == 1 and np.isinf(ref[0, 2])    # reads inf at crl=2 -> occlusion
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching HIP (the reference has UB instead)."""
+    import ctypes as C
+    from stereo_match_traditional_amd._lib import lib, strerror
+    L = lib()
+    h = C.c_void_p()
+    assert L.smt_adcensus_create(0, 10, 16, C.c_float(10), C.c_float(30), C.byref(h)) == -1
+    assert L.smt_adcensus_create(10, 10, 300, C.c_float(10), C.c_float(30), C.byref(h)) == -1     # D > 256
+    assert L.smt_adcensus_create(10, 10, 16, C.c_float(0), C.c_float(30), C.byref(h)) == -1
+    assert L.smt_adcensus_compute(None, None, None, 3, None, None) == -1
+    assert L.smt_wta(None, 4, 4, 4, None, None) == -1
+    assert L.smt_crossarm_create(4, 4, 0, None, C.byref(h)) == -1
+    assert L.smt_scanline_create(4, 4, 8, 10, 150, None) == -1
+    assert L.smt_crossagg_create(0, 4, 8, C.byref(h)) == -1          # Initialize returns false (:28-31)
+    assert L.smt_lrcheck(None, None, 4, 4, 2, None, None, None) == -1
+    assert L.smt_sad(None, None, 4, 4, 8, 1, 1, None, None) == -1
+    assert L.smt_ncc(None, None, 4, 4, 8, 1, None, None, None) == -1
+    assert L.smt_asw(None, None, 4, 4, 8, 1, None, None, 40, 1, None, None, None) == -1
+    assert strerror(-5).startswith("reference behaviour undefined")
+    # host-only helpers work without a GPU
+    sp = (C.c_double * 25)()
+    cm = (C.c_double * 256)()
+    assert L.smt_asw_masks(1, C.c_double(50), C.c_double(30), sp, cm) == 0
+    assert abs(sp[12] - 1.0) < 1e-15 and cm[0] == 1.0
+    cls = (C.c_uint8 * 6)(0, 1, 2, 2, 0, 1)
+    occ = (C.c_int * 12)()
+    mis = (C.c_int * 12)()
+    no, nm = C.c_int(), C.c_int()
+    assert L.smt_lrcheck_lists(cls, 2, 3, occ, C.byref(no), mis, C.byref(nm)) == 0
+    assert (no.value, nm.value) == (2, 2) and list(occ[:4]) == [0, 1, 1, 2] and list(mis[:4]) == [0, 2, 1, 0]
+
+
+def test_host_mirror_asw_masks_match_oracle(O):
+    import ctypes as C
+    from stereo_match_traditional_amd._lib import lib
+    for ws, ss, sc in ((1, 50.0, 30.0), (11, 50.0, 30.0), (16, 10.0, 7.5)):
+        side = 2 * ws + 3
+        sp = np.empty((side, side), np.float64)
+        cm = np.empty(256, np.float64)
+        assert lib().smt_asw_masks(ws, C.c_double(ss), C.c_double(sc), sp.ctypes.data_as(C.c_void_p),
+                                   cm.ctypes.data_as(C.c_void_p)) == 0
+        rs, rc = O.asw_masks(ws, ss, sc)
+        assert np.array_equal(sp, rs) and np.array_equal(cm, rc)
