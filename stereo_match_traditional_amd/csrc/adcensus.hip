@@ -292,14 +292,17 @@ __global__ void __launch_bounds__(NT) k_cost(int H, int W, int D, Tables T, int 
 // address directly; the WTA is a DPP min over the cost bit patterns (costs are >= +0, so
 // uint order == float order) + ballot + scalar pick, no LDS round trips; the FPW winners
 // are collected one per lane and stored once per wave.
-constexpr int FTJ = 128;          // pixels per workgroup
+#ifndef SMT_FTJ
+#define SMT_FTJ 64
+#endif
+constexpr int FTJ = SMT_FTJ;      // pixels per workgroup
 constexpr int FPW = FTJ / 4;      // consecutive pixels per wave
 
 struct __attribute__((aligned(16))) Anchor { uint64_t cen, mask; };
 
 template <int C, int VIEW>
-__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float *__restrict__ vol,
-                                                  float *__restrict__ disp)
+__device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, float *__restrict__ vol,
+                                               float *__restrict__ disp)
 {
     constexpr int D = 64 * C;
     constexpr int NX = FTJ + D;
@@ -384,10 +387,15 @@ __global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float 
             c[k] = *(const float *)(lutA + ad4) + lutC[hd];
             key[k] = __float_as_uint(c[k]);
         }
+#ifdef SMT_NT_STORE
+#pragma unroll
+        for (int k = 0; k < C; k++) __builtin_nontemporal_store(c[k], out + k);
+#else
         vecf<C> pk;
 #pragma unroll
         for (int k = 0; k < C; k++) pk.v[k] = c[k];
         *reinterpret_cast<vecf<C> *>(out) = pk;
+#endif
         out += D;
 
         if (disp) {
@@ -416,6 +424,23 @@ __global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float 
         }
     }
     if (disp && lane < npx) disp[(size_t)i * W + j0 + p0 + lane] = (float)res;
+}
+
+template <int C, int VIEW>
+__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float *__restrict__ vol,
+                                                  float *__restrict__ disp)
+{
+    cost_fast_body<C, VIEW>(H, W, T, vol, disp);
+}
+
+// both views in one launch: blockIdx.z selects the view (no gap / tail between two launches)
+template <int C>
+__global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, Tables T, float *__restrict__ vol0,
+                                                   float *__restrict__ vol1, float *__restrict__ disp0,
+                                                   float *__restrict__ disp1)
+{
+    if (blockIdx.z == 0) cost_fast_body<C, 0>(H, W, T, vol0, disp0);
+    else cost_fast_body<C, 1>(H, W, T, vol1, disp1);
 }
 
 // generic WTA over an existing volume: one wave per pixel.
@@ -589,6 +614,14 @@ template <int C>
 static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
 {
     dim3 grid((h->W + FTJ - 1) / FTJ, h->H);
+#ifndef SMT_SPLIT_VIEWS
+    if (views == SMT_VIEW_BOTH) {
+        dim3 g2(grid.x, grid.y, 2);
+        hipLaunchKernelGGL((k_cost_fast2<C>), g2, dim3(NT), 0, h->stream, h->H, h->W, h->T, h->vol[0],
+                           h->vol[1], dL, dR);
+        return;
+    }
+#endif
     if (views & SMT_VIEW_LEFT)
         hipLaunchKernelGGL((k_cost_fast<C, 0>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->T,
                            h->vol[0], dL);
