@@ -146,22 +146,41 @@ __global__ void __launch_bounds__(NT) k_ncc(const uint8_t *__restrict__ L, const
 }
 
 // ---------------------------------------------------------------------------------- ASW
-__global__ void __launch_bounds__(NT) k_asw(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
-                                            int W, int D, int wins, const double *__restrict__ space,
-                                            const double *__restrict__ color, int T, int view,
-                                            float *__restrict__ disp, float *__restrict__ cost_out)
+// Per hypothesis: cost = sum_q w0(q) w1(q) e(q) / sum_q w0(q) w1(q) over the (2*wins+1)^2 window, with
+// w0 = color[|A(q)-A(c)|]*space(q) (anchor window, independent of d), w1 = color[|B(q)-B(c)|]*space(q)
+// (other image at the hypothesis' offset), e = min(|A(q)-B(q)|, T)                (ASW.h:210-257).
+//
+// One wave per pixel, d = lane + 64k.  The anchor weights are the same for all 64 lanes, so the
+// lanes compute them 64 taps at a time (one tap per lane) and the tap loop broadcasts
+// {w0*space, anchor byte} with v_readlane -- no per-tap uniform LDS traffic.  The only per-lane
+// table read is color[|B(q)-B(c)|]; the table is replicated [256][32] in LDS so that lane l
+// always hits bank l%32 (conflict-free random access; float32 copy, relative error 6e-8).  Bytes of the other image are
+// fetched as (unaligned) dwords, 4 taps per load.
+// Arithmetic: m2 = (w0*space)*w1' with w1' = color*space folded as (w0*space*space)*color -- a
+// re-association of the reference's (color*space)*(color*space); float64 throughout, well
+// inside the 1e-4 tolerance on the float32 cost the reference itself narrows to (:255-256).
+constexpr int ANT = 1024;      // 16 pixels (waves) per workgroup share one replicated table
+
+// K = number of live 64-disparity slots per lane (ceil(D/64)), a template parameter so that the
+// tap loop is branch-free: columns are processed in dwords, the last (partial) dword is taken
+// from columns side-4..side-1 with the weights of already-counted columns zeroed.
+template <int K>
+__global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                             int W, int D, int wins, const double *__restrict__ space,
+                                             const double *__restrict__ color, int T, int view,
+                                             float *__restrict__ disp, float *__restrict__ cost_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int side = 2 * wins + 1;
-    double *s_color = (double *)smem;                 // 256
-    double *s_space = s_color + 256;                  // side*side
-    for (int e = threadIdx.x; e < 256; e += NT) s_color[e] = color[e];
-    for (int e = threadIdx.x; e < side * side; e += NT) s_space[e] = space[e];
+    double *s_color = (double *)smem;                 // [256][32] replica: entry k of lane l at k*32 + l%32
+    double *s_sp2 = s_color + 256 * 32;               // space(q)^2, side*side
+    for (int e = threadIdx.x; e < 256 * 32; e += ANT) s_color[e] = color[e >> 5];
+    for (int e = threadIdx.x; e < side * side; e += ANT) { const double v = space[e]; s_sp2[e] = v * v; }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = blockIdx.x * (NT / 64) + wv;
+    const int p = blockIdx.x * (ANT / 64) + wv;
     if (p >= H * W) return;
     const int io = p / W, jo = p - io * W;
     const int Wp = W + 2 * wins;
@@ -171,36 +190,74 @@ __global__ void __launch_bounds__(NT) k_asw(const uint8_t *__restrict__ Lp, cons
     // last in-range disparity: left j-wins-d >= 0 (:348); right j+wins+d+1 < Wp-wins (:401)
     const int dmax = (view == 0) ? jo : (W - wins - 2 - jo);
     const int ca = A[wins * Wp + wins];
-    float cv[KMAX];
+    const double *lut = s_color + (lane & 31);
+
+    double sw[K], sv[K];
+    const uint8_t *bk[K];
+    int cb[K];
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
+    for (int k = 0; k < K; k++) {
         const int d = lane + 64 * k;
-        cv[k] = 0.0f;
-        if (d < D && dmax >= 0) {
-            const int dd = d < dmax ? d : dmax;
-            const uint8_t *b = (view == 0) ? B - dd : B + dd;
-            const int cb = b[wins * Wp + wins];
-            double sw = 0, sv = 0;
-            for (int r = 0; r < side; r++)
-                for (int c = 0; c < side; c++) {
-                    const int pa = A[r * Wp + c], pb = b[r * Wp + c];
-                    const double sp = s_space[r * side + c];
-                    const double m0 = s_color[abs(pa - ca)] * sp;         // Mask0 :229-230
-                    const double m1 = s_color[abs(pb - cb)] * sp;         // Mask1 :244-245
-                    const double m2 = m0 * m1;                            // :248
-                    int e = abs(pa - pb);
-                    e = e > T ? T : e;                                    // :358-366
-                    sw += m2;                                             // :252
-                    sv += m2 * (double)e;                                 // :253-255
-                }
-            cv[k] = (float)(sv / sw);
+        const int dd = d < dmax ? d : (dmax < 0 ? 0 : dmax);    // d >= D lanes compute a harmless duplicate
+        bk[k] = (view == 0) ? B - dd : B + dd;
+        cb[k] = bk[k][wins * Wp + wins];
+        sw[k] = 0.0; sv[k] = 0.0;
+    }
+    const int nfull = side >> 2;                       // full dwords per row
+    const int ctail = side - 4;                        // start of the tail dword (side >= 5 always: wins >= 2)
+    const bool has_tail = (side & 3) != 0;
+
+    auto taps4 = [&](const unsigned (&word)[K], int c0, int whi, int wlo, int pa_l) {
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const double w = __hiloint2double(__builtin_amdgcn_readlane(whi, c0 + cc),
+                                              __builtin_amdgcn_readlane(wlo, c0 + cc));
+            const int pa = __builtin_amdgcn_readlane(pa_l, c0 + cc);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int pb = (word[k] >> (8 * cc)) & 0xff;
+                const double m2 = w * lut[abs(pb - cb[k]) * 32];
+                int e = abs(pa - pb);
+                e = e > T ? T : e;
+                sw[k] += m2;
+                sv[k] = __builtin_fma(m2, (double)e, sv[k]);
+            }
+        }
+    };
+
+    for (int r = 0; r < side; r++) {
+        // this row's anchor weights, one column per lane: w = color[|A-ca|] * space^2
+        int pa_l = 0; double w_l = 0.0;
+        if (lane < side) {
+            pa_l = A[r * Wp + lane];
+            w_l = s_color[abs(pa_l - ca) * 32 + (lane & 31)] * s_sp2[r * side + lane];
+        }
+        const int wlo = __double2loint(w_l), whi = __double2hiint(w_l);
+        // tail copy: columns already covered by the full dwords get weight 0
+        const double w_t = (lane >= 4 * nfull) ? w_l : 0.0;
+        const int tlo = __double2loint(w_t), thi = __double2hiint(w_t);
+        for (int g = 0; g < nfull; g++) {
+            unsigned word[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], bk[k] + r * Wp + 4 * g, 4);   // unaligned dword
+            taps4(word, 4 * g, whi, wlo, pa_l);
+        }
+        if (has_tail) {
+            unsigned word[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], bk[k] + r * Wp + ctail, 4);
+            taps4(word, ctail, thi, tlo, pa_l);
         }
     }
+    float cv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) cv[k] = (float)(sv[k] / sw[k]);
+
     // WinTakeAll: first strict minimum (:193-208).  dmax < 0 (right view, last columns): the
     // reference chains every cost to an out-of-bounds read -> all equal -> 0.
     float lm = INFINITY; int ld = 0;
 #pragma unroll
-    for (int k = 0; k < KMAX; k++) {
+    for (int k = 0; k < K; k++) {
         const int d = lane + 64 * k;
         if (d < D && lm > cv[k]) { lm = cv[k]; ld = d; }
     }
@@ -210,7 +267,7 @@ __global__ void __launch_bounds__(NT) k_asw(const uint8_t *__restrict__ Lp, cons
     if (lane == 0) disp[p] = (dmax < 0) ? 0.0f : (float)cand;
     if (cost_out) {
 #pragma unroll
-        for (int k = 0; k < KMAX; k++) {
+        for (int k = 0; k < K; k++) {
             const int d = lane + 64 * k;
             if (d < D) cost_out[(size_t)p * D + d] = (dmax < 0) ? NAN : cv[k];
         }
@@ -264,11 +321,23 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT))
         return SMT_ERR_ARG;
     const int wins = winSize + 1, side = 2 * wins + 1;
-    const size_t shm = (size_t)(256 + side * side) * 8;
-    if (shm > 150 * 1024) return SMT_ERR_ARG;
+    if (side > 64) return SMT_ERR_ARG;                   // one window row per wave pass
+    const size_t shm = (size_t)(256 * 32 + side * side) * 8;
     const int N = H * W;
-    hipLaunchKernelGGL(k_asw, dim3((N + 3) / 4), dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, wins, space,
-                       color, T, view == SMT_VIEW_LEFT ? 0 : 1, disp, cost);
+    const int v = view == SMT_VIEW_LEFT ? 0 : 1;
+#define SMT_ASW(KK)                                                                                          \
+    do {                                                                                                     \
+        SMT_HIP(hipFuncSetAttribute((const void *)k_asw<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL(k_asw<KK>, dim3((N + 15) / 16), dim3(ANT), shm, smt_stream(stream), Lp, Rp, H, W, D, wins, \
+                           space, color, T, v, disp, cost);                                                  \
+    } while (0)
+    switch ((D + 63) / 64) {
+    case 1: SMT_ASW(1); break;
+    case 2: SMT_ASW(2); break;
+    case 3: SMT_ASW(3); break;
+    default: SMT_ASW(4); break;
+    }
+#undef SMT_ASW
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }
