@@ -289,6 +289,21 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
 int smt_asw_crosscheck(const float *dispL, const float *dispR, int H, int W, uint8_t *out,
                        void *stream);
 
+/* =====================================================================================
+ * Either side of the path: input staging and the first post-filter
+ * ===================================================================================== */
+/* cvtColor(CV_BGR2GRAY) as the drivers call it (AD-CensusV1/main.cpp:19-20): OpenCV 3.1.0's
+ * 8-bit fixed-point rule (1868 B + 9617 G + 4899 R + 8192) >> 14.  bgr uint8 [H][W][3]. */
+int smt_bgr2gray(const uint8_t *bgr, int H, int W, uint8_t *gray, void *stream);
+/* copyMakeBorder(..., BORDER_REPLICATE) with equal borders (SADmain.cpp:47-48, ASWeight.cpp:54-57).
+ * dst uint8 [H+2*pad][W+2*pad]. */
+int smt_pad_replicate(const uint8_t *src, int H, int W, int pad, uint8_t *dst, void *stream);
+/* uchar -> float image copy (main.cpp:46-55). */
+int smt_u8_to_f32(const uint8_t *src, int H, int W, float *dst, void *stream);
+/* MedianFilter(in, out, width, height, wnd_size) (AD-CensusV1/PostProcessing.h:314-344): median of
+ * the in-image part of the window, element [n/2] of the ascending order.  wnd_size <= 7. */
+int smt_median_filter(const float *in, float *out, int W, int H, int wnd_size, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,3 +279,20 @@ def asw_crosscheck(dL, dR):
     out = np.empty((H, W), np.uint8)
     lib().orc_asw_crosscheck(_p(dL), _p(dR), H, W, _p(out))
     return out
+
+
+# --------------------------------------------------------------------------- staging / post
+def bgr2gray(bgr):
+    bgr = _c(bgr, np.uint8)
+    H, W, _ = bgr.shape
+    g = np.empty((H, W), np.uint8)
+    lib().orc_bgr2gray(_p(bgr), H * W, _p(g))
+    return g
+
+
+def median(inp, wnd):
+    inp = _c(inp, np.float32)
+    H, W = inp.shape
+    out = np.empty_like(inp)
+    lib().orc_median(_p(inp), _p(out), W, H, wnd)
+    return out

@@ -836,6 +836,42 @@ ORC_API void orc_asw_crosscheck(const float *dL, const float *dR, int H, int W, 
         }
 }
 
+/* ------------------------------------------------------------------------------------
+ * 8f n1/n2  staging + MedianFilter
+ *   cvtColor(CV_BGR2GRAY): OpenCV 3.1.0 RGB2Gray<uchar> fixed point (third-party, not in this
+ *   image; restated from its published source): (1868 B + 9617 G + 4899 R + 8192) >> 14.
+ *   MedianFilter: AD-CensusV1/PostProcessing.h:314-344.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_bgr2gray(const uint8_t *bgr, int n, uint8_t *gray)
+{
+    for (int p = 0; p < n; p++)
+        gray[p] = (uint8_t)((1868 * bgr[3 * p] + 9617 * bgr[3 * p + 1] + 4899 * bgr[3 * p + 2] + (1 << 13)) >> 14);
+}
+
+static int orc_cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+ORC_API void orc_median(const float *in, float *out, int W, int H, int wnd)
+{
+    int radius = wnd / 2;                                              /* :317 */
+    float *buf = (float *)malloc((size_t)wnd * wnd * sizeof(float));
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            int n = 0;
+            for (int r = -radius; r <= radius; r++)
+                for (int c = -radius; c <= radius; c++) {
+                    int row = i + r, col = j + c;
+                    if (row >= 0 && row < H && col >= 0 && col < W) buf[n++] = in[row * W + col];   /* :333-335 */
+                }
+            qsort(buf, n, sizeof(float), orc_cmp_float);               /* std::sort :339 */
+            out[i * W + j] = buf[n / 2];                               /* :341 */
+        }
+    free(buf);
+}
+
 /* FNV-1a 64 over raw bytes: fixture hashes */
 ORC_API uint64_t orc_fnv1a(const void *p, size_t n)
 {

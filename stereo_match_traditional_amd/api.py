@@ -14,7 +14,8 @@ from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 __all__ = ["AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
-           "AdaptiveSupportWeight", "asw_CrossCheckDiaparity"]
+           "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
+           "to_float", "MedianFilter"]
 
 
 def current_stream_ptr():
@@ -502,4 +503,43 @@ def asw_CrossCheckDiaparity(leftdisp, rightdisp):
     out = torch.empty((H, W), dtype=torch.uint8, device=leftdisp.device)
     check(lib().smt_asw_crosscheck(_ptr(leftdisp), _ptr(rightdisp), H, W, _ptr(out), current_stream_ptr()),
           "smt_asw_crosscheck")
+    return out
+
+
+# ======================================================================================
+# Either side of the path: input staging and the first post-filter
+# ======================================================================================
+def cvtColor_BGR2GRAY(bgr):
+    """cvtColor(img, gray, CV_BGR2GRAY) (main.cpp:19-20); uint8 [H][W][3] -> uint8 [H][W]."""
+    H, W, _ = bgr.shape
+    _dev(bgr, torch.uint8, (H, W, 3), "bgr")
+    gray = torch.empty((H, W), dtype=torch.uint8, device=bgr.device)
+    check(lib().smt_bgr2gray(_ptr(bgr), H, W, _ptr(gray), current_stream_ptr()), "smt_bgr2gray")
+    return gray
+
+
+def copyMakeBorder_replicate(img, pad):
+    """copyMakeBorder(img, out, pad, pad, pad, pad, BORDER_REPLICATE) (SADmain.cpp:47-48)."""
+    H, W = img.shape
+    _dev(img, torch.uint8, (H, W), "img")
+    out = torch.empty((H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=img.device)
+    check(lib().smt_pad_replicate(_ptr(img), H, W, int(pad), _ptr(out), current_stream_ptr()), "smt_pad_replicate")
+    return out
+
+
+def to_float(img):
+    """uchar -> float copy of main.cpp:46-55."""
+    H, W = img.shape
+    _dev(img, torch.uint8, (H, W), "img")
+    out = torch.empty((H, W), dtype=torch.float32, device=img.device)
+    check(lib().smt_u8_to_f32(_ptr(img), H, W, _ptr(out), current_stream_ptr()), "smt_u8_to_f32")
+    return out
+
+
+def MedianFilter(inp, width, height, wnd_size):
+    """PostProcessing.h:314-344."""
+    _dev(inp, torch.float32, (height, width), "in")
+    out = torch.empty_like(inp)
+    check(lib().smt_median_filter(_ptr(inp), _ptr(out), width, height, int(wnd_size), current_stream_ptr()),
+          "smt_median_filter")
     return out

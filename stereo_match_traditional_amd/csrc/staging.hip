@@ -1,0 +1,104 @@
+// Data formats either side of the path: what the reference's main()s do
+// right before and right after the hot path, so a caller can stay on the device.
+//   - BGR -> gray: cvtColor(CV_BGR2GRAY) (AD-CensusV1/main.cpp:19-20, CBLSM.cpp:21-22).  OpenCV 3.1.0
+//     (not in this image; pinned by */*.vcxproj linker lines) computes 8-bit gray in fixed point:
+//     (1868*B + 9617*G + 4899*R + (1 << 13)) >> 14   (RGB2Gray<uchar>, yuv_shift = 14).
+//   - replicate padding: copyMakeBorder(BORDER_REPLICATE) (SADmain.cpp:47-48, ASWeight.cpp:54-57).
+//   - uchar -> float staging (main.cpp:46-55).
+//   - MedianFilter (AD-CensusV1/PostProcessing.h:314-344): sort the in-image part of the
+//     wnd x wnd window, take element [n/2].
+#include "smt_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ void __launch_bounds__(NT) k_bgr2gray(const uint8_t *__restrict__ bgr, int n, uint8_t *__restrict__ gray)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n) return;
+    const int b = bgr[3 * p], g = bgr[3 * p + 1], r = bgr[3 * p + 2];
+    gray[p] = (uint8_t)((1868 * b + 9617 * g + 4899 * r + (1 << 13)) >> 14);
+}
+
+__global__ void __launch_bounds__(NT) k_pad(const uint8_t *__restrict__ src, int H, int W, int pad,
+                                            uint8_t *__restrict__ dst)
+{
+    const int Wp = W + 2 * pad, Hp = H + 2 * pad;
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= Hp * Wp) return;
+    const int ip = p / Wp, jp = p - ip * Wp;
+    int i = ip - pad, j = jp - pad;
+    i = i < 0 ? 0 : (i > H - 1 ? H - 1 : i);
+    j = j < 0 ? 0 : (j > W - 1 ? W - 1 : j);
+    dst[p] = src[(size_t)i * W + j];
+}
+
+__global__ void __launch_bounds__(NT) k_u8_to_f32(const uint8_t *__restrict__ src, int n, float *__restrict__ dst)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p < n) dst[p] = (float)src[p];                                    // static_cast<float>(uchar), main.cpp:52-53
+}
+
+// one thread per pixel; window <= 7x7.  std::sort's result on floats (with +inf, no NaN) is the
+// ascending order, so element [n/2] is order-independent of the sort algorithm.
+__global__ void __launch_bounds__(NT) k_median(const float *__restrict__ in, float *__restrict__ out, int W, int H,
+                                               int radius)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= W * H) return;
+    const int i = p / W, j = p - i * W;
+    float v[49];
+    int n = 0;
+    for (int r = -radius; r <= radius; r++)
+        for (int c = -radius; c <= radius; c++) {
+            const int row = i + r, col = j + c;
+            if (row >= 0 && row < H && col >= 0 && col < W) {
+                // insertion into the sorted prefix
+                const float x = in[(size_t)row * W + col];
+                int k = n++;
+                while (k > 0 && v[k - 1] > x) { v[k] = v[k - 1]; k--; }
+                v[k] = x;
+            }
+        }
+    out[p] = v[n / 2];
+}
+
+}  // namespace
+
+SMT_API int smt_bgr2gray(const uint8_t *bgr, int H, int W, uint8_t *gray, void *stream)
+{
+    if (!bgr || !gray || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_bgr2gray, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), bgr, n, gray);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_pad_replicate(const uint8_t *src, int H, int W, int pad, uint8_t *dst, void *stream)
+{
+    if (!src || !dst || H <= 0 || W <= 0 || pad < 0) return SMT_ERR_ARG;
+    const int n = (H + 2 * pad) * (W + 2 * pad);
+    hipLaunchKernelGGL(k_pad, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), src, H, W, pad, dst);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_u8_to_f32(const uint8_t *src, int H, int W, float *dst, void *stream)
+{
+    if (!src || !dst || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), src, n, dst);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_median_filter(const float *in, float *out, int W, int H, int wnd_size, void *stream)
+{
+    if (!in || !out || in == out || H <= 0 || W <= 0 || wnd_size < 1 || wnd_size > 7) return SMT_ERR_ARG;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_median, dim3((n + NT - 1) / NT), dim3(NT), 0, smt_stream(stream), in, out, W, H,
+                       wnd_size / 2);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
