@@ -303,6 +303,11 @@ int smt_u8_to_f32(const uint8_t *src, int H, int W, float *dst, void *stream);
 /* MedianFilter(in, out, width, height, wnd_size) (AD-CensusV1/PostProcessing.h:314-344): median of
  * the in-image part of the window, element [n/2] of the ascending order.  wnd_size <= 7. */
 int smt_median_filter(const float *in, float *out, int W, int H, int wnd_size, void *stream);
+/* RemoveSpeckles(disparity_map, width, height, diff_insame, min_speckle_aera, invalid_val)
+ * (AD-CensusV1/PostProcessing.h:250-311), in place.  invalid_val is an int as in the reference
+ * (its call sites pass +inf: undefined conversion, INT_MIN on x86).  Synchronising. */
+int smt_remove_speckles(float *disparity_map, int W, int H, int diff_insame, unsigned min_speckle_area,
+                        int invalid_val, void *stream);
 
 #ifdef __cplusplus
 }

@@ -296,3 +296,10 @@ def median(inp, wnd):
     out = np.empty_like(inp)
     lib().orc_median(_p(inp), _p(out), W, H, wnd)
     return out
+
+
+def remove_speckles(d, diff, min_area, invalid_val):
+    d = np.array(d, np.float32, copy=True, order="C")
+    H, W = d.shape
+    lib().orc_remove_speckles(_p(d), W, H, int(diff), C.c_uint(min_area), int(invalid_val))
+    return d

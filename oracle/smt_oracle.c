@@ -872,6 +872,44 @@ ORC_API void orc_median(const float *in, float *out, int W, int H, int wnd)
     free(buf);
 }
 
+/* RemoveSpeckles                                          PostProcessing.h:250-311 */
+ORC_API void orc_remove_speckles(float *d, int W, int H, int diff, unsigned min_area, int invalid_val)
+{
+    size_t n = (size_t)W * H;
+    uint8_t *visited = (uint8_t *)calloc(n, 1);
+    int *vec = (int *)malloc(n * sizeof(int));
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            if (visited[i * W + j] || d[i * W + j] == invalid_val) continue;      /* :262 float == int */
+            size_t sz = 0, cur = 0, next;
+            vec[sz++] = i * W + j;
+            visited[i * W + j] = 1;
+            do {
+                next = sz;
+                for (size_t k = cur; k < next; k++) {
+                    int row = vec[k] / W, col = vec[k] % W;
+                    float base = d[row * W + col];
+                    for (int r = -1; r <= 1; r++)
+                        for (int c = -1; c <= 1; c++) {
+                            if (r == 0 && c == 0) continue;
+                            int rr = row + r, cc = col + c;
+                            if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+                                if (!visited[rr * W + cc] && d[rr * W + cc] != invalid_val &&
+                                    fabsf(d[rr * W + cc] - base) <= diff) {           /* :290-292 */
+                                    vec[sz++] = rr * W + cc;
+                                    visited[rr * W + cc] = 1;
+                                }
+                            }
+                        }
+                }
+                cur = next;
+            } while (next < sz);
+            if (sz < min_area)
+                for (size_t k = 0; k < sz; k++) d[vec[k]] = (float)invalid_val;     /* :304-308 */
+        }
+    free(visited); free(vec);
+}
+
 /* FNV-1a 64 over raw bytes: fixture hashes */
 ORC_API uint64_t orc_fnv1a(const void *p, size_t n)
 {

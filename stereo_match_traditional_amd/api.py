@@ -15,7 +15,7 @@ __all__ = ["AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cbl
            "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
-           "to_float", "MedianFilter"]
+           "to_float", "MedianFilter", "RemoveSpeckles"]
 
 
 def current_stream_ptr():
@@ -543,3 +543,11 @@ def MedianFilter(inp, width, height, wnd_size):
     check(lib().smt_median_filter(_ptr(inp), _ptr(out), width, height, int(wnd_size), current_stream_ptr()),
           "smt_median_filter")
     return out
+
+
+def RemoveSpeckles(disparity_map, width, height, diff_insame, min_speckle_aera, invalid_val):
+    """PostProcessing.h:250-311, in place.  invalid_val: int, as in the reference's signature."""
+    _dev(disparity_map, torch.float32, (height, width), "disparity_map")
+    check(lib().smt_remove_speckles(_ptr(disparity_map), width, height, int(diff_insame), C.c_uint(min_speckle_aera),
+                                    int(invalid_val), current_stream_ptr()), "smt_remove_speckles")
+    return disparity_map

@@ -102,3 +102,112 @@ SMT_API int smt_median_filter(const float *in, float *out, int W, int H, int wnd
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// RemoveSpeckles (AD-CensusV1/PostProcessing.h:250-311): 8-connected regions of pixels whose
+// neighbouring disparities differ by <= diff_insame; regions smaller than min_speckle_aera are
+// set to invalid_val.  The reference grows regions by BFS in scan order, but membership is the
+// transitive closure of a SYMMETRIC relation on the unmodified input (pixels it invalidates were
+// already visited), so the partition is order-independent: connected-component labelling by
+// min-label propagation + pointer jumping, saturating size counts, then the invalidation pass.
+// `invalid_val` is an int as in the reference's signature (`const int&`; its call sites pass
+// +inf, whose int conversion is undefined -- INT_MIN on x86).
+namespace {
+
+__device__ __forceinline__ bool sp_linked(float a, float b, float inv, float diff)
+{
+    return a != inv && b != inv && fabsf(b - a) <= diff;                  // :290-292
+}
+
+__global__ void __launch_bounds__(NT) k_cc_init(int n, int *label, int *count)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p < n) { label[p] = p; count[p] = 0; }
+}
+
+__global__ void __launch_bounds__(NT) k_cc_scan(const float *__restrict__ d, int W, int H, float inv, float diff,
+                                                int *label, int *changed)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= W * H) return;
+    const float dp = d[p];
+    if (dp == inv) return;
+    const int i = p / W, j = p - i * W;
+    const int lp = label[p];
+    int m = lp;
+    for (int r = -1; r <= 1; r++)
+        for (int c = -1; c <= 1; c++) {
+            if (r == 0 && c == 0) continue;
+            const int ii = i + r, jj = j + c;
+            if (ii < 0 || ii >= H || jj < 0 || jj >= W) continue;
+            const int q = ii * W + jj;
+            if (sp_linked(dp, d[q], inv, diff)) m = min(m, label[q]);
+        }
+    if (m < lp) {
+        atomicMin(&label[lp], m);          // hook this pixel's current root under the smaller label
+        atomicMin(&label[p], m);
+        *changed = 1;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_cc_jump(int n, int *label)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n) return;
+    int l = label[p];
+    while (label[l] != l) l = label[l];
+    label[p] = l;
+}
+
+__global__ void __launch_bounds__(NT) k_cc_count(const float *__restrict__ d, int n, float inv, const int *label,
+                                                 int *count, int cap)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n || d[p] == inv) return;
+    const int l = label[p];
+    if (*(volatile int *)&count[l] < cap) atomicAdd(&count[l], 1);     // saturating: only "< min area?" matters
+}
+
+__global__ void __launch_bounds__(NT) k_cc_apply(float *d, int n, float inv, const int *label, const int *count,
+                                                 int min_area)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n || d[p] == inv) return;
+    if ((unsigned)count[label[p]] < (unsigned)min_area) d[p] = inv;     // :304-308
+}
+
+}  // namespace
+
+SMT_API int smt_remove_speckles(float *disp, int W, int H, int diff_insame, unsigned min_speckle_area,
+                                int invalid_val, void *stream)
+{
+    if (!disp || W <= 0 || H <= 0) return SMT_ERR_ARG;
+    hipStream_t st = smt_stream(stream);
+    const int n = W * H;
+    int *label = nullptr, *count = nullptr, *flag = nullptr;
+    int rc = smt_malloc((void **)&label, (size_t)n * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&count, (size_t)n * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&flag, 4);
+    if (rc != SMT_OK) { (void)hipFree(label); (void)hipFree(count); (void)hipFree(flag); return rc; }
+    const float inv = (float)invalid_val, diff = (float)diff_insame;
+    const dim3 grid((n + NT - 1) / NT);
+    hipLaunchKernelGGL(k_cc_init, grid, dim3(NT), 0, st, n, label, count);
+    rc = SMT_OK;
+    for (int it = 0; it < n; it++) {                  // converges in far fewer rounds; n bounds it
+        int h = 0;
+        if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) { rc = SMT_ERR_HIP; break; }
+        hipLaunchKernelGGL(k_cc_scan, grid, dim3(NT), 0, st, disp, W, H, inv, diff, label, flag);
+        hipLaunchKernelGGL(k_cc_jump, grid, dim3(NT), 0, st, n, label);
+        if (hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = SMT_ERR_HIP; break; }
+        if (!h) break;
+    }
+    if (rc == SMT_OK) {
+        const int cap = min_speckle_area > 0x7fffffffu ? 0x7fffffff : (int)min_speckle_area;
+        hipLaunchKernelGGL(k_cc_count, grid, dim3(NT), 0, st, disp, n, inv, label, count, cap);
+        hipLaunchKernelGGL(k_cc_apply, grid, dim3(NT), 0, st, disp, n, inv, label, count, cap);
+        if (hipStreamSynchronize(st) != hipSuccess) rc = SMT_ERR_HIP;
+    }
+    (void)hipFree(label); (void)hipFree(count); (void)hipFree(flag);
+    return rc;
+}
