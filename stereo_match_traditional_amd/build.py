@@ -37,14 +37,17 @@ def build(force=False, verbose=False):
 
 
 def build_host():
-    """C++ host mirror (host/smt_host.hpp) + the main.cpp counterpart, plain g++ against the C ABI."""
-    exe = os.path.join(HERE, "lib", "adcensus_main")
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(HERE, "host", "adcensus_main.cpp"),
-           "-o", exe, "-L" + os.path.join(HERE, "lib"), "-lsmt_hip", "-Wl,-rpath,$ORIGIN"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("host build failed:\n" + r.stdout + r.stderr)
-    return exe
+    """C++ host mirror (host/smt_host.hpp) + the main.cpp counterparts, plain g++ against the C ABI."""
+    exes = []
+    for name in ("adcensus_main", "matchers_main"):
+        exe = os.path.join(HERE, "lib", name)
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(HERE, "host", name + ".cpp"),
+               "-o", exe, "-L" + os.path.join(HERE, "lib"), "-lsmt_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build failed:\n" + r.stdout + r.stderr)
+        exes.append(exe)
+    return exes
 
 
 if __name__ == "__main__":

@@ -265,4 +265,83 @@ private:
     std::vector<CrossArm> host_arms_;
 };
 
+// ------------------------------------------------------------------ window matchers (host buffers)
+// Images are the caller's replicate-padded uint8 buffers, exactly what the reference's drivers pass
+// after copyMakeBorder (SADmain.cpp:47-48, ASWeight.cpp:54-57); rows/cols are the PADDED sizes like
+// Mat::rows/cols in the reference signatures.
+
+// GetPointDepthLeft / GetPointDepthRight (Sad.h:96-182): disparity is int32 [rows-2w][cols-2w], w = winsize+1
+inline void GetPointDepth(int *disparity, const unsigned char *leftimg, const unsigned char *rightimg, int rows,
+                          int cols, int MaxDisparity, int winsize, bool left_view)
+{
+    const int w = winsize + 1, H = rows - 2 * w, W = cols - 2 * w;
+    DevBuf<unsigned char> L((size_t)rows * cols), R((size_t)rows * cols);
+    DevBuf<int> d((size_t)H * W);
+    L.upload(leftimg); R.upload(rightimg);
+    check(smt_sad(L.get(), R.get(), H, W, MaxDisparity, winsize, left_view ? SMT_VIEW_LEFT : SMT_VIEW_RIGHT, d.get(),
+                  nullptr), "smt_sad");
+    d.download(disparity);
+}
+inline void GetPointDepthLeft(int *disparity, const unsigned char *l, const unsigned char *r, int rows, int cols,
+                              int MaxDisparity, int winsize) { GetPointDepth(disparity, l, r, rows, cols, MaxDisparity, winsize, true); }
+inline void GetPointDepthRight(int *disparity, const unsigned char *l, const unsigned char *r, int rows, int cols,
+                               int MaxDisparity, int winsize) { GetPointDepth(disparity, l, r, rows, cols, MaxDisparity, winsize, false); }
+
+// NCC_algorithem(leftImage, rigthImage, width, height, disp, winSize, dispRange) (NCC.h:69-95)
+inline void NCC_algorithem(const unsigned char *leftImage, const unsigned char *rigthImage, int width, int height,
+                           int *disp, int winSize, int dispRange)
+{
+    const size_t n = (size_t)width * height;
+    DevBuf<unsigned char> L(n), R(n);
+    DevBuf<int> d(n);
+    L.upload(leftImage); R.upload(rigthImage);
+    check(smt_ncc(L.get(), R.get(), height, width, dispRange, winSize, d.get(), nullptr, nullptr), "smt_ncc");
+    d.download(disp);
+}
+
+// getGausssianMask + getColorMask (ASW.h:16-47)
+inline void getMasks(std::vector<double> &spaceMask, std::vector<double> &colorMask, int winSize, double spaceSigma,
+                     double colorSigma)
+{
+    const int side = 2 * winSize + 3;
+    spaceMask.assign((size_t)side * side, 0.0);
+    colorMask.assign(256, 0.0);
+    check(smt_asw_masks(winSize, spaceSigma, colorSigma, spaceMask.data(), colorMask.data()), "smt_asw_masks");
+}
+
+// AdaptiveSupportWeight / AdaptiveSupportWeightRight (ASW.h:329-431); disp float [rows-2w][cols-2w], w = winSize+1
+inline void AdaptiveSupportWeight(float *disp, const unsigned char *leftGray, const unsigned char *rightGray, int rows,
+                                  int cols, int winSize, int dispRange, const std::vector<double> &space,
+                                  const std::vector<double> &color, int T, bool left_view = true)
+{
+    const int w = winSize + 1, H = rows - 2 * w, W = cols - 2 * w;
+    DevBuf<unsigned char> L((size_t)rows * cols), R((size_t)rows * cols);
+    DevBuf<double> sp(space.size()), cm(color.size());
+    DevBuf<float> d((size_t)H * W);
+    L.upload(leftGray); R.upload(rightGray); sp.upload(space.data()); cm.upload(color.data());
+    check(smt_asw(L.get(), R.get(), H, W, dispRange, winSize, sp.get(), cm.get(), T,
+                  left_view ? SMT_VIEW_LEFT : SMT_VIEW_RIGHT, d.get(), nullptr, nullptr), "smt_asw");
+    d.download(disp);
+}
+
+// MedianFilter / RemoveSpeckles (PostProcessing.h:250-344) on host maps
+inline void MedianFilter(const float *in, float *out, const int &width, const int &height, const int wnd_size)
+{
+    const size_t n = (size_t)width * height;
+    DevBuf<float> a(n), b(n);
+    a.upload(in);
+    check(smt_median_filter(a.get(), b.get(), width, height, wnd_size, nullptr), "smt_median_filter");
+    b.download(out);
+}
+inline void RemoveSpeckles(float *disparity_map, const int &width, const int &height, const int &diff_insame,
+                           const unsigned int &min_speckle_aera, const int &invalid_val)
+{
+    const size_t n = (size_t)width * height;
+    DevBuf<float> a(n);
+    a.upload(disparity_map);
+    check(smt_remove_speckles(a.get(), width, height, diff_insame, min_speckle_aera, invalid_val, nullptr),
+          "smt_remove_speckles");
+    a.download(disparity_map);
+}
+
 }  // namespace smt

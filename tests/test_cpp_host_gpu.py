@@ -30,3 +30,21 @@ def test_main_cpp_counterpart(smt, O):
     for k, v in exp.items():
         assert got[k] == f"{O.fnv1a(v):016x}", k
     assert int(got["n_occlusion"]) == no and int(got["n_mismatch"]) == nm
+
+
+def test_matchers_main_counterpart(smt, O):
+    exe = os.path.join(ROOT, "stereo_match_traditional_amd", "lib", "matchers_main")
+    assert os.path.exists(exe)
+    H, W, D, seed = 40, 90, 32, 5
+    r = subprocess.run([exe, str(H), str(W), str(D), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.split() for line in r.stdout.strip().splitlines())
+    L, R = O.synth_pair(H, W, D, seed)
+    Lp, Rp = O.pad_replicate(L, 4), O.pad_replicate(R, 4)
+    exp = {"sad_left": O.sad(Lp, Rp, D, 3, 0), "sad_right": O.sad(Lp, Rp, D, 3, 1), "ncc": O.ncc(L, R, D, 3)}
+    sp, cm = O.asw_masks(3, 50.0, 30.0)
+    al, ar = O.asw(Lp, Rp, D, 3, sp, cm, 40, 0), O.asw(Lp, Rp, D, 3, sp, cm, 40, 1)
+    exp.update({"asw_left": al, "asw_right": ar, "median": O.median(al, 3),
+                "speckles": O.remove_speckles(al, 1, 30, -(2 ** 31))})
+    for k, v in exp.items():
+        assert got[k] == f"{O.fnv1a(v):016x}", k
