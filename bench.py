@@ -65,8 +65,8 @@ def pmc_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="adcensus_1080p_d192", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs-per-step", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows in the CPU-baseline sample (0 = skip)")

@@ -24,38 +24,47 @@ __device__ __forceinline__ bool lr_rejected(const float *dL, const float *dR, in
     return true;                                                          // :128-131
 }
 
+// grid-stride over pixels; class counts are reduced per workgroup (one atomic per class and
+// workgroup -- per-wave atomics on two addresses cost 0.5 ms at 1080p)
 __global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL, const float *__restrict__ dR,
                                                     int H, int W, float thr, uint8_t *__restrict__ cls,
                                                     int *counts)
 {
-    const int p = blockIdx.x * NT + threadIdx.x;
-    const bool live = p < H * W;
-    const int i = live ? p / W : 0, j = live ? p - i * W : 0;
-    const int row0 = i * W;
-    const float d = live ? dL[p] : 0.0f;
-    uint8_t c = 0;
-    if (!live) c = 0;
-    else if (d == INFINITY) c = 2;
-    else {
-        const int cr = (int)((double)((float)j - d) + 0.5);
-        if (cr >= 0 && cr < W) {
-            const float dr = dR[row0 + cr];
-            if (fabsf(d - dr) > thr) {
-                const int crl = (int)((double)((float)cr + dr) + 0.5);    // :110
-                if (crl > 0 && crl < W) {
-                    float dl = dL[row0 + crl];
-                    if (crl < j && lr_rejected(dL, dR, row0, crl, W, thr)) dl = INFINITY;
-                    c = (dl > d) ? 1 : 2;                                 // :113-118
-                } else c = 2;
-            }
-        } else c = 2;
+    __shared__ int s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = H * W;
+    int n1 = 0, n2 = 0;
+    for (int p = blockIdx.x * NT + threadIdx.x; p < n; p += gridDim.x * NT) {
+        const int i = p / W, j = p - i * W;
+        const int row0 = i * W;
+        const float d = dL[p];
+        uint8_t c = 0;
+        if (d == INFINITY) c = 2;
+        else {
+            const int cr = (int)((double)((float)j - d) + 0.5);
+            if (cr >= 0 && cr < W) {
+                const float dr = dR[row0 + cr];
+                if (fabsf(d - dr) > thr) {
+                    const int crl = (int)((double)((float)cr + dr) + 0.5);    // :110
+                    if (crl > 0 && crl < W) {
+                        float dl = dL[row0 + crl];
+                        if (crl < j && lr_rejected(dL, dR, row0, crl, W, thr)) dl = INFINITY;
+                        c = (dl > d) ? 1 : 2;                                 // :113-118
+                    } else c = 2;
+                }
+            } else c = 2;
+        }
+        cls[p] = c;
+        n1 += (c == 1); n2 += (c == 2);
     }
-    if (live) cls[p] = c;
-    if (counts) {                                          // one atomic per wave and class
-        const int n1 = __popcll(__ballot(c == 1)), n2 = __popcll(__ballot(c == 2));
-        if ((threadIdx.x & 63) == 0) {
-            if (n1) atomicAdd(&counts[0], n1);
-            if (n2) atomicAdd(&counts[1], n2);
+    if (counts) {
+        if (n1) atomicAdd(&s_cnt[0], n1);
+        if (n2) atomicAdd(&s_cnt[1], n2);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_cnt[0]) atomicAdd(&counts[0], s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&counts[1], s_cnt[1]);
         }
     }
 }
@@ -102,8 +111,8 @@ SMT_API int smt_lrcheck(float *dL, const float *dR, int H, int W, int gate, uint
     hipStream_t st = smt_stream(stream);
     const int n = H * W;
     if (counts) SMT_HIP(hipMemsetAsync(counts, 0, 8, st));
-    hipLaunchKernelGGL(k_lr_classify, dim3((n + NT - 1) / NT), dim3(NT), 0, st, dL, dR, H, W, (float)gate, cls,
-                       counts);
+    const int blocks = (n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048;
+    hipLaunchKernelGGL(k_lr_classify, dim3(blocks), dim3(NT), 0, st, dL, dR, H, W, (float)gate, cls, counts);
     hipLaunchKernelGGL(k_lr_apply, dim3((n + NT - 1) / NT), dim3(NT), 0, st, dL, cls, n);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
