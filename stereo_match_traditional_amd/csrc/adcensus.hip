@@ -25,6 +25,7 @@
 #include "smt_common.h"
 #include <math.h>
 #include <new>
+#include <type_traits>
 
 namespace {
 
@@ -353,76 +354,86 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
     const int p0 = wid * FPW;
     const int dl = lane * C;
     // ext entry of (pixel p, hypothesis dl+k):  VIEW 0: p + (D-1) - dl - k ;  VIEW 1: p + dl + k
+    // With E(n) = staged entry e0 + n, pixel q needs  VIEW 0: E(q-k)  /  VIEW 1: E(q+k), k = 0..C-1.
+    // The C live entries sit in a register ring R[n mod C] = E(n); the pixel loop is unrolled by C so
+    // every ring index is a compile-time constant (no register shuffling), and one new entry is
+    // fetched per pixel.
     const int e0 = (VIEW == 0) ? (p0 + (D - 1) - dl) : (p0 + dl);
-    uint64_t wc[C];
-    unsigned wv[C];
+    uint64_t rc[C];
+    unsigned rv[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
-        const int e = (VIEW == 0) ? (e0 - k) : (e0 + k);
-        wc[k] = s_cenx[e];
-        wv[k] = s_valx[e];
+        // ring slot of E(n) is n mod C;  VIEW 0 starts with E(0), E(-1), ..., E(-(C-1));  VIEW 1 with E(0..C-1)
+        const int n = (VIEW == 0) ? -k : k;
+        const int slot = ((n % C) + C) % C;
+        rc[slot] = s_cenx[e0 + n];
+        rv[slot] = s_valx[e0 + n];
     }
     const char *lutA = (const char *)s_lut;
     const float *lutC = s_lut + 256;
     float *out = vol + ((size_t)i * W + j0 + p0) * D + dl;
     int res = 0;
     const int npx = min(FPW, W - (j0 + p0));                 // uniform; may be <= 0
+    // interior run: every pixel of this wave has all 63 taps inside the image, so the tap mask is
+    // all ones and the two ANDs per hypothesis can be dropped (bit 63 is 0 in every table entry)
+    const bool interior = (i >= 4) && (i < H - 4) && (j0 + p0 >= 3) && (j0 + p0 + npx - 1 <= W - 4);
 
-    for (int q = 0; q < npx; q++) {
-        const int p = p0 + q;
-        const Anchor a = s_anc[p];
-        const unsigned va = s_vala[p];
-        // the entry that enters the window at the next pixel (always inside the staged range)
-        const int en = (VIEW == 0) ? (e0 + q + 1) : (e0 + q + C);
-        const uint64_t nc = s_cenx[en];
-        const unsigned nv = s_valx[en];
-
-        float c[C];
-        unsigned key[C];
+    auto run = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        for (int g = 0; g < npx; g += C) {
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-            const uint64_t x = (a.cen ^ wc[k]) & a.mask;
-            const int hd = __popcll(x);
-            const unsigned ad4 = __builtin_amdgcn_sad_u16(va, wv[k], 0u);   // 4*|va - vx|
-            c[k] = *(const float *)(lutA + ad4) + lutC[hd];
-            key[k] = __float_as_uint(c[k]);
+            for (int u = 0; u < C; u++) {
+                const int q = g + u;
+                if (q < npx) {
+                    const int p = p0 + q;
+                    const Anchor a = s_anc[p];
+                    const unsigned va = s_vala[p];
+                    // entry that joins the ring for the next pixel (always inside the staged range)
+                    const int nn = (VIEW == 0) ? (q + 1) : (q + C);
+                    const uint64_t nc = s_cenx[e0 + nn];
+                    const unsigned nv = s_valx[e0 + nn];
+                    float c[C];
+                    unsigned key[C];
+#pragma unroll
+                    for (int k = 0; k < C; k++) {
+                        // E(q-k) / E(q+k) with q = u (mod C)
+                        constexpr int dummy = 0; (void)dummy;
+                        const int slot = (VIEW == 0) ? (((u - k) % C) + C) % C : (u + k) % C;
+                        uint64_t x = a.cen ^ rc[slot];
+                        if (MASKED) x &= a.mask;
+                        const int hd = __popcll(x);
+                        const unsigned ad4 = __builtin_amdgcn_sad_u16(va, rv[slot], 0u);   // 4*|va - vx|
+                        c[k] = *(const float *)(lutA + ad4) + lutC[hd];
+                        key[k] = __float_as_uint(c[k]);
+                    }
+                    vecf<C> pk;
+#pragma unroll
+                    for (int k = 0; k < C; k++) pk.v[k] = c[k];
+                    *reinterpret_cast<vecf<C> *>(out) = pk;
+                    out += D;
+                    if (disp) {
+                        unsigned ml = key[0];
+#pragma unroll
+                        for (int k = 1; k < C; k++) ml = min(ml, key[k]);
+                        const unsigned m = wave_min_u32(ml);
+                        const unsigned long long b = __ballot(ml == m);
+                        const int first = __builtin_ctzll(b);
+                        int kk = C - 1;
+#pragma unroll
+                        for (int k = C - 2; k >= 0; k--)
+                            if ((unsigned)__builtin_amdgcn_readlane((int)key[k], first) == m) kk = k;
+                        const int wd = first * C + kk;       // wave-uniform
+                        res = (lane == q) ? wd : res;
+                    }
+                    // the new entry replaces the one that just left the window
+                    const int ns = (VIEW == 0) ? (u + 1) % C : u % C;
+                    rc[ns] = nc; rv[ns] = nv;
+                }
+            }
         }
-#ifdef SMT_NT_STORE
-#pragma unroll
-        for (int k = 0; k < C; k++) __builtin_nontemporal_store(c[k], out + k);
-#else
-        vecf<C> pk;
-#pragma unroll
-        for (int k = 0; k < C; k++) pk.v[k] = c[k];
-        *reinterpret_cast<vecf<C> *>(out) = pk;
-#endif
-        out += D;
-
-        if (disp) {
-            unsigned ml = key[0];
-#pragma unroll
-            for (int k = 1; k < C; k++) ml = min(ml, key[k]);
-            const unsigned m = wave_min_u32(ml);
-            const unsigned long long b = __ballot(ml == m);
-            const int first = __builtin_ctzll(b);
-            int kk = C - 1;
-#pragma unroll
-            for (int k = C - 2; k >= 0; k--)
-                if ((unsigned)__builtin_amdgcn_readlane((int)key[k], first) == m) kk = k;
-            const int wd = first * C + kk;                   // wave-uniform
-            res = (lane == q) ? wd : res;
-        }
-        // slide the window
-        if (VIEW == 0) {
-#pragma unroll
-            for (int k = C - 1; k >= 1; k--) { wc[k] = wc[k - 1]; wv[k] = wv[k - 1]; }
-            wc[0] = nc; wv[0] = nv;
-        } else {
-#pragma unroll
-            for (int k = 0; k < C - 1; k++) { wc[k] = wc[k + 1]; wv[k] = wv[k + 1]; }
-            wc[C - 1] = nc; wv[C - 1] = nv;
-        }
-    }
+    };
+    if (interior) run(std::false_type{});
+    else run(std::true_type{});
     if (disp && lane < npx) disp[(size_t)i * W + j0 + p0 + lane] = (float)res;
 }
 
