@@ -148,3 +148,297 @@ def test_host_mirror_asw_masks_match_oracle(O):
                                    cm.ctypes.data_as(C.c_void_p)) == 0
         rs, rc = O.asw_masks(ws, ss, sc)
         assert np.array_equal(sp, rs) and np.array_equal(cm, rc)
+
+
+# ----------------------------------------------------------------------------------------------
+# Independent restatements of SURVEY.md Appendix A (which the surveyor checked against a build of
+# the reference) vs the loop-for-loop oracle.  Different formulation, same answers expected.
+# ----------------------------------------------------------------------------------------------
+def _arms_appendix_a4(img, tau0=30, low=6, sec=17, maxlen=34, row_bug=True):
+    """A.4 in its PARALLEL form: per direction find the first row-major pixel whose neighbours
+    1..17 are in-image and within tau0; pixels before it use tau0, it switches at k=18, later ones use 6;
+    tau stays 6 for all later directions."""
+    H, W = img.shape
+    I = img.astype(np.int64)
+    out = []
+    tau_in = tau0
+    for dirn in range(4):
+        colR = H if (dirn == 1 and row_bug) else W
+        def nb(i, j, k):
+            if dirn == 0: return (i, j - k) if j - k >= 0 else None
+            if dirn == 1: return (i, j + k) if j + k < colR else None
+            if dirn == 2: return (i - k, j) if i - k >= 0 else None
+            return (i + k, j) if i + k < H else None
+        def far(i, j):
+            return [j - 1 >= 1, j + 1 < colR - 1, i - 1 >= 1, i + 1 < H - 1][dirn]
+        F = None
+        if tau_in == tau0:
+            for i in range(H):
+                for j in range(colR):
+                    ok = True
+                    for k in range(1, sec + 1):
+                        q = nb(i, j, k)
+                        if q is None or abs(I[i, j] - I[q]) > tau0:
+                            ok = False
+                            break
+                    if ok:
+                        F = i * colR + j
+                        break
+                if F is not None:
+                    break
+        arm = np.zeros(H * W, np.int32)
+        for i in range(H):
+            for j in range(colR):
+                idx = i * colR + j
+                if tau_in == low or (F is not None and idx > F):
+                    tA = tB = low
+                elif F is not None and idx == F:
+                    tA, tB = tau0, low
+                else:
+                    tA = tB = tau0
+                saved, k = 0, 0
+                while True:
+                    k += 1
+                    saved = k - 1
+                    if k > sec and k > maxlen:
+                        break
+                    q = nb(i, j, k)
+                    if q is None:
+                        break
+                    if abs(I[i, j] - I[q]) > (tB if k > sec else tA):
+                        if far(i, j) and saved < 1:
+                            saved = 1
+                        break
+                arm[idx] = saved
+        out.append(arm.reshape(H, W))
+        if F is not None:
+            tau_in = low
+    return out
+
+
+def test_arms_parallel_form_equals_sequential_oracle(O):
+    rng = np.random.default_rng(4)
+    for kind in range(3):
+        H, W = 26, 60
+        if kind == 0:
+            img = ((np.add.outer(np.arange(H) // 9, np.arange(W) // 23) * 17) % 200 + 20 + rng.integers(0, 3, (H, W))).astype(np.uint8)
+        elif kind == 1:
+            img = rng.integers(0, 256, (H, W)).astype(np.uint8)
+        else:
+            img = np.tile((rng.integers(0, 2, W) * 120 + 40).astype(np.uint8), (H, 1))   # flips only in the top pass
+        ref = O.arms_all(img)
+        got = _arms_appendix_a4(img)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+
+
+def test_scanline_formula_a6_equals_oracle(O):
+    """A.6 written as array code per line (not pointer walking)."""
+    rng = np.random.default_rng(6)
+    H, W, D, p1, p2i = 5, 7, 6, 10, 150
+    C = (rng.random((H, W, D)) * 2).astype(np.float32)
+    G = rng.integers(0, 256, (H, W)).astype(np.float32)
+    f32 = np.float32
+
+    def line(costs, grays, updown):
+        n = len(costs)
+        out = np.zeros((n, D), np.float32)
+        out[0] = costs[0]
+        last = np.full(D + 2, 65535, np.float32)
+        last[1:D + 1] = costs[0]
+        minlast = f32(min(last))
+        gprev = grays[0]
+        for s in range(1, n):
+            p2 = max(f32(p1), f32(p2i) / f32(abs(f32(grays[s]) - f32(gprev)) + f32(1)))
+            if not updown:
+                gprev = grays[s]
+            cur = np.zeros(D, np.float32)
+            for d in range(D):
+                l1 = last[d + 1]
+                l2 = f32((last[d + 1] if updown else last[d]) + f32(p1))
+                l3 = f32(last[d + 2] + f32(p1))
+                l4 = f32(minlast + p2)
+                cur[d] = f32(f32(costs[s][d] + min(min(l1, l2), min(l3, l4))) - minlast)
+            out[s] = cur
+            minlast = f32(min(f32(65535), cur.min()))
+            last[1:D + 1] = cur
+        return out
+
+    Lv = np.zeros_like(C); Rv = np.zeros_like(C); Uv = np.zeros_like(C); Dv = np.zeros_like(C)
+    flatG = G.reshape(-1)
+    for i in range(H):
+        Lv[i] = line(C[i], G[i], False)
+        Rv[i] = line(C[i, ::-1], G[i, ::-1], False)[::-1]
+    for j in range(W):
+        Uv[:, j] = line(C[:, j], flatG[j:j + H], True)                        # gray pointer steps by ONE element
+        start = (H - 1) * W + j
+        Dv[:, j] = line(C[::-1, j], flatG[start - (H - 1):start + 1][::-1], True)[::-1]
+    for name, v in (("left", Lv), ("right", Rv), ("up", Uv), ("down", Dv)):
+        assert np.array_equal(v.view(np.uint32), O.scan_pass(C, G, p1, p2i, name).view(np.uint32)), name
+    tot = ((Lv + Rv) + Uv) + Dv
+    assert np.array_equal(tot.view(np.uint32), O.scanline(C, G, p1, p2i).view(np.uint32))
+
+
+def test_lrcheck_two_phase_a7_equals_oracle(O):
+    rng = np.random.default_rng(8)
+    H, W, gate = 9, 40, 2
+    dL = rng.integers(0, 20, (H, W)).astype(np.float32)
+    dR = rng.integers(0, 20, (H, W)).astype(np.float32)
+    dL[rng.random((H, W)) < 0.06] = np.inf
+    ref, cls, no, nm = O.lrcheck(dL, dR, gate)
+
+    def rejected(i, x):
+        d = dL[i, x]
+        if np.isinf(d):
+            return True
+        cr = int(np.float64(np.float32(x) - d) + 0.5)
+        if 0 <= cr < W:
+            return abs(d - dR[i, cr]) > gate
+        return True
+    got = np.zeros((H, W), np.uint8)
+    for i in range(H):
+        for j in range(W):
+            d = dL[i, j]
+            if np.isinf(d):
+                got[i, j] = 2
+                continue
+            cr = int(np.float64(np.float32(j) - d) + 0.5)
+            if not (0 <= cr < W):
+                got[i, j] = 2
+                continue
+            dr = dR[i, cr]
+            if abs(d - dr) > gate:
+                crl = int(np.float64(np.float32(cr) + dr) + 0.5)
+                if 0 < crl < W:
+                    dl = np.inf if (crl < j and rejected(i, crl)) else dL[i, crl]
+                    got[i, j] = 1 if dl > d else 2
+                else:
+                    got[i, j] = 2
+    assert np.array_equal(got, cls)
+    assert np.array_equal(np.isinf(ref), got != 0)
+
+
+def test_aggregation_a5_equals_oracle(O):
+    rng = np.random.default_rng(10)
+    H, W, D = 72, 160, 3
+    img = ((np.add.outer(np.arange(H) // 9, np.arange(W) // 23) * 17) % 200 + 20 + rng.integers(0, 3, (H, W))).astype(np.uint8)
+    vol = rng.random((H, W, D), dtype=np.float32)
+    arms = O.arms_all(img)
+    ref, oob = O.aggregate_rect(vol, arms, 0)
+    assert oob == 0
+    flat = vol.reshape(H * W, D)
+    f32 = np.float32
+    for (i, j) in [(0, 0), (5, 17), (20, 100), (36, 159), (71, 3), (40, 80)]:
+        Ll, Rr, up, dn = [int(a[i, j]) for a in arms]
+        for d in range(D):
+            v = f32(0)
+            for l in range(-Ll, Rr + 1):
+                for t in range(-up, dn + 1):
+                    v = f32(v + flat[(i + t) * W + j + l, d])
+            assert f32(v / f32((Ll + Rr + 1) * (up + dn + 1))) == ref[i, j, d]
+
+
+def test_sad_a8_numpy_equals_oracle(O):
+    """A.8: replicate-padded SAD, left-edge copy rule, OptimalDisparity; right view's unwritten last
+    row/column and plain first-min."""
+    H, W, D, winsize = 12, 30, 20, 1
+    L, R = O.synth_pair(H, W, 32, 3)
+    w = winsize + 1
+    Lp, Rp = np.pad(L, w, mode="edge").astype(np.int64), np.pad(R, w, mode="edge").astype(np.int64)
+    side = 2 * w + 1
+    exp_l = np.zeros((H, W), np.int32)
+    exp_r = np.zeros((H, W), np.int32)
+    for i in range(H):
+        for j in range(W):
+            sad = np.zeros(D, np.float32)
+            for d in range(D):
+                dd = min(d, j)
+                sad[d] = np.abs(Lp[i:i + side, j:j + side] - Rp[i:i + side, j - dd:j - dd + side]).sum()
+            minv, best = np.float32(65535), np.float32(65535)
+            for d in range(1, D):
+                if minv > sad[d]:
+                    minv, best = sad[d], np.float32(d)
+            sec = sad[0]
+            for d in range(D):
+                if sad[d] != minv:
+                    sec = min(sec, sad[d])
+            if float(sec - minv) <= 0.01 or best == 0 or best == D - 1:
+                exp_l[i, j] = 0
+            else:
+                exp_l[i, j] = int(best)
+            if i < H - 1 and j < W - 1:
+                sr = np.zeros(D, np.float32)
+                for d in range(D):
+                    dd = min(d, W - 1 - j)
+                    sr[d] = np.abs(Lp[i:i + side, j + dd:j + dd + side] - Rp[i:i + side, j:j + side]).sum()
+                exp_r[i, j] = int(np.argmin(sr))
+    assert np.array_equal(O.sad(Lp.astype(np.uint8), Rp.astype(np.uint8), D, winsize, 0), exp_l)
+    assert np.array_equal(O.sad(Lp.astype(np.uint8), Rp.astype(np.uint8), D, winsize, 1), exp_r)
+
+
+def test_ncc_a9_numpy_equals_oracle(O):
+    H, W, D, win = 14, 30, 12, 2
+    L, R = O.synth_pair(H, W, 32, 4)
+    L = L.copy(); R = R.copy()
+    L[2:11, 4:20] = 77; R[2:11, 0:24] = 77            # flat -> NaN
+    disp, cost = O.ncc(L, R, D, win, want_cost=True)
+    Ld, Rd = L.astype(np.float64), R.astype(np.float64)
+    for i in range(win, H - win):
+        for j in range(win, W - win):
+            c = np.empty(D)
+            for d in range(D):
+                if j - win - d >= 0:
+                    a = Ld[i - win:i + win + 1, j - win:j + win + 1]
+                    b = Rd[i - win:i + win + 1, j - win - d:j + win - d + 1]
+                    x, y = a - a.sum() / a.size, b - b.sum() / b.size
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        c[d] = (x * y).sum() / (np.sqrt((x * x).sum()) * np.sqrt((y * y).sum()))
+                else:
+                    c[d] = 255.0
+            ok = ~np.isnan(c)
+            assert np.array_equal(np.isnan(cost[i, j]), ~ok)
+            assert np.allclose(cost[i, j][ok], c[ok], rtol=0, atol=1e-9)
+            best, m = 0, np.float32(cost[i, j][0])
+            for d in range(1, D):
+                if np.float64(m) < cost[i, j][d]:
+                    best, m = d, np.float32(cost[i, j][d])
+            assert disp[i, j] == best
+    assert disp[:win].sum() == 0 and disp[:, :win].sum() == 0
+
+
+def test_asw_a11_numpy_equals_oracle(O):
+    H, W, D, ws, T = 8, 26, 10, 1, 40
+    L, R = O.synth_pair(H, W, 32, 5)
+    wins = ws + 1
+    Lp, Rp = np.pad(L, wins, mode="edge"), np.pad(R, wins, mode="edge")
+    sp, cm = O.asw_masks(ws, 50.0, 30.0)
+    side = 2 * wins + 1
+    c = (side - 1) // 2
+    yy, xx = np.mgrid[0:side, 0:side]
+    assert np.array_equal(sp, np.exp(-(((xx - c) ** 2 + (yy - c) ** 2).astype(np.float64)) / (2 * 50.0 * 50.0)))
+    for view in (0, 1):
+        disp, cost = O.asw(Lp, Rp, D, ws, sp, cm, T, view, want_cost=True)
+        A, B = (Lp, Rp) if view == 0 else (Rp, Lp)
+        Wp = W + 2 * wins
+        for i in range(H):
+            for j in range(W):
+                a = A[i:i + side, j:j + side].astype(np.int64)
+                dmax = j if view == 0 else W - wins - 2 - j
+                if dmax < 0:
+                    assert disp[i, j] == 0 and np.isnan(cost[i, j]).all()
+                    continue
+                cv = np.empty(D, np.float32)
+                for d in range(D):
+                    dd = min(d, dmax)
+                    x0 = j - dd if view == 0 else j + dd
+                    b = B[i:i + side, x0:x0 + side].astype(np.int64)
+                    w0 = cm[np.abs(a - a[wins, wins])] * sp
+                    w1 = cm[np.abs(b - b[wins, wins])] * sp
+                    m2 = w0 * w1
+                    e = np.minimum(np.abs(a - b), T)
+                    cv[d] = np.float32((m2 * e).sum() / m2.sum())
+                assert np.max(np.abs(cv - cost[i, j])) <= 1e-5
+                # identical WTA unless two costs are within float noise of each other
+                srt = np.sort(cv)
+                if srt[1] - srt[0] > 1e-5:
+                    assert disp[i, j] == int(np.argmin(cv))
