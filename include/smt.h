@@ -71,9 +71,10 @@ int smt_stream_destroy(void *stream);
 int smt_stream_sync(void *stream); /* synchronising */
 
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------
- * When enabled, every pair processed on the handle records three HIP events on the
- * handle's stream (before the table kernels, between tables and cost kernel, after the
- * cost kernel) into a ring of `SMT_TIMING_SLOTS` slots; nothing synchronises until
+ * When enabled, every pair processed on the handle records four HIP events -- around the table
+ * kernels on the handle's internal stream and around the cost kernel(s) on the caller's stream, i.e.
+ * each on the stream the kernels are launched on -- into a ring of `SMT_TIMING_SLOTS` slots; nothing
+ * synchronises until
  * smt_adcensus_kernel_times, which waits for the last event and returns the per-pair
  * durations in milliseconds, oldest first. */
 #define SMT_TIMING_SLOTS 1024
@@ -106,7 +107,9 @@ int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R, int vi
 
 /* Same, for a batch of `pairs` image pairs laid out [pairs][H][W]; the volumes are
  * reused per pair (only the last pair's stay readable), the disparity maps are
- * [pairs][H][W].  This is the sharding unit of the multi-GPU configuration. */
+ * [pairs][H][W].  This is the sharding unit of the multi-GPU configuration.  The census tables
+ * are double-buffered inside the handle and built on an internal stream, so pair b+1's table
+ * kernels overlap pair b's cost kernel. */
 int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
                                int views, float *dispL, float *dispR);
 

@@ -108,6 +108,31 @@ def test_batch_matches_single(smt, O):
     adc.close()
 
 
+def test_batch_overlap_many_pairs(smt, O):
+    """9 pairs through the double-buffered table sets (tables of pair b+1 built on the internal
+    stream while pair b's cost kernel runs): every map and the last pair's volumes must be right,
+    twice in a row on the same handle."""
+    H, W, D, B = 24, 200, 64, 9
+    dev = torch.device("cuda:0")
+    Ls, Rs = zip(*[O.synth_pair(H, W, D, 500 + b, noise=(b % 3 == 0)) for b in range(B)])
+    Lb = torch.from_numpy(np.stack(Ls).astype(np.float32)).to(dev)
+    Rb = torch.from_numpy(np.stack(Rs).astype(np.float32)).to(dev)
+    adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, 10.0, 30.0)
+    refs = [(O.adcensus_view(Ls[b], Rs[b], D, 10.0, 30.0, 0), O.adcensus_view(Ls[b], Rs[b], D, 10.0, 30.0, 1))
+            for b in range(B)]
+    for _ in range(2):
+        dl = torch.full((B, H, W), -1.0, device=dev)
+        dr = torch.full((B, H, W), -1.0, device=dev)
+        adc.ComputeBatch(Lb, Rb, dl, dr)
+        adc.status()
+        for b in range(B):
+            assert np.array_equal(dl[b].cpu().numpy(), O.wta(refs[b][0])), b
+            assert np.array_equal(dr[b].cpu().numpy(), O.wta(refs[b][1])), b
+        assert np.array_equal(adc.GetPtrLeft().cpu().numpy().view(np.uint32), refs[B - 1][0].view(np.uint32))
+        assert np.array_equal(adc.GetPtrRight().cpu().numpy().view(np.uint32), refs[B - 1][1].view(np.uint32))
+    adc.close()
+
+
 def test_domain_flag(smt):
     from stereo_match_traditional_amd import SmtError
     dev = torch.device("cuda:0")
