@@ -117,8 +117,8 @@ int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, 
  * destroy. view = SMT_VIEW_LEFT or SMT_VIEW_RIGHT. */
 int smt_adcensus_volume(smt_adcensus *h, int view, float **vol);
 
-/* Test hook: D that are multiples of 64 normally take the register-window kernel; on != 0
- * routes them through the general (any D) kernel as well so both stay covered. */
+/* Test hook: on != 0 routes the pair through the first-version table-lookup kernel (a second,
+ * independent formulation kept for cross-checking) instead of the register-window kernel. */
 int smt_adcensus_force_generic(smt_adcensus *h, int on);
 
 /* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen so far was not an

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(NT) k_cost(int H, int W, int D, Tables T, int 
     }
 }
 
-// ---- fast path: D == 64*C ---------------------------------------------------------------
+// ---- production path (any D <= 256; FULL specialisation for D == 64*C) -------------------
 // Same mapping (one wave per pixel, lane l owns d = l*C..l*C+C-1) with the instruction count
 // cut down: VIEW is a template parameter; each wave walks FPW CONSECUTIVE pixels so that
 // a lane's C ext operands form a register sliding window (one new LDS entry per pixel
@@ -301,17 +301,26 @@ constexpr int FPW = FTJ / 4;      // consecutive pixels per wave
 
 struct __attribute__((aligned(16))) Anchor { uint64_t cen, mask; };
 
-template <int C, int VIEW>
-__device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, float *__restrict__ vol,
+// FULL: D == 64*C (no lane / element predication anywhere).  Otherwise C = ceil(D/64): lanes whose
+// first hypothesis is >= D compute a harmless duplicate of lane 0, elements past D are neither
+// stored nor allowed to win the WTA, and the staged arrays carry XPAD spare entries on both sides for
+// the window slots those elements would touch.
+template <int C, int VIEW, bool FULL>
+__device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tables &T, float *__restrict__ vol,
                                                float *__restrict__ disp)
 {
-    constexpr int D = 64 * C;
-    constexpr int NX = FTJ + D;
+    constexpr int DM = 64 * C;                               // largest D this instantiation serves
+    constexpr int XPAD = 4;
+    constexpr int NXM = FTJ + DM + 2 * XPAD;
+    const int D = FULL ? DM : Drt;
+    const int NX = FTJ + D;
     __shared__ Anchor s_anc[FTJ];
-    __shared__ uint64_t s_cenx[NX];
+    __shared__ uint64_t s_cenx_raw[NXM];
     __shared__ float s_lut[320];
-    __shared__ uint16_t s_valx[NX];
+    __shared__ uint16_t s_valx_raw[NXM];
     __shared__ uint16_t s_vala[FTJ];
+    uint64_t *s_cenx = s_cenx_raw + XPAD;                    // entry e in [-XPAD, NX + XPAD)
+    uint16_t *s_valx = s_valx_raw + XPAD;
 
     const int i = blockIdx.y;
     const int j0 = blockIdx.x * FTJ;
@@ -324,7 +333,7 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
         const uint8_t *extv = T.u8[VIEW ^ 1] + (size_t)i * W;
         const uint8_t *ancv = T.u8[VIEW] + (size_t)i * W;
         const int xbase = (VIEW == 0) ? (j0 - (D - 1)) : j0;
-        for (int e = tid; e < NX; e += NT) {
+        for (int e = tid - (FULL ? 0 : XPAD); e < NX + (FULL ? 0 : XPAD); e += NT) {
             const int x = xbase + e;
             int xc, xv;
             if (VIEW == 0) {
@@ -332,8 +341,8 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
                 xv = xc < 0 ? 0 : xc;
                 xc += 3;
             } else {
-                xc = x > W + 3 ? W + 3 : x;
-                xv = x > W - 1 ? W - 1 : x;
+                xc = x > W + 3 ? W + 3 : (x < 0 ? 0 : x);
+                xv = x > W - 1 ? W - 1 : (x < 0 ? 0 : x);
             }
             s_cenx[e] = cenX[xc];
             s_valx[e] = (uint16_t)(4u * extv[xv]);
@@ -352,7 +361,11 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
     __syncthreads();
 
     const int p0 = wid * FPW;
-    const int dl = lane * C;
+    const int dlr = lane * C;                                // first hypothesis of this lane
+    const int dl = (FULL || dlr < D) ? dlr : 0;              // lanes entirely past D shadow lane 0
+    bool ok[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) ok[k] = FULL || (dlr + k < D);
     // ext entry of (pixel p, hypothesis dl+k):  VIEW 0: p + (D-1) - dl - k ;  VIEW 1: p + dl + k
     // With E(n) = staged entry e0 + n, pixel q needs  VIEW 0: E(q-k)  /  VIEW 1: E(q+k), k = 0..C-1.
     // The C live entries sit in a register ring R[n mod C] = E(n); the pixel loop is unrolled by C so
@@ -371,7 +384,7 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
     }
     const char *lutA = (const char *)s_lut;
     const float *lutC = s_lut + 256;
-    float *out = vol + ((size_t)i * W + j0 + p0) * D + dl;
+    float *out = vol + ((size_t)i * W + j0 + p0) * D + dlr;
     int res = 0;
     const int npx = min(FPW, W - (j0 + p0));                 // uniform; may be <= 0
     // interior run: every pixel of this wave has all 63 taps inside the image, so the tap mask is
@@ -404,12 +417,18 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
                         const int hd = __popcll(x);
                         const unsigned ad4 = __builtin_amdgcn_sad_u16(va, rv[slot], 0u);   // 4*|va - vx|
                         c[k] = *(const float *)(lutA + ad4) + lutC[hd];
-                        key[k] = __float_as_uint(c[k]);
+                        key[k] = ok[k] ? __float_as_uint(c[k]) : 0xFFFFFFFFu;
                     }
-                    vecf<C> pk;
+                    if (FULL) {
+                        vecf<C> pk;
 #pragma unroll
-                    for (int k = 0; k < C; k++) pk.v[k] = c[k];
-                    *reinterpret_cast<vecf<C> *>(out) = pk;
+                        for (int k = 0; k < C; k++) pk.v[k] = c[k];
+                        *reinterpret_cast<vecf<C> *>(out) = pk;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < C; k++)
+                            if (ok[k]) out[k] = c[k];
+                    }
                     out += D;
                     if (disp) {
                         unsigned ml = key[0];
@@ -437,43 +456,48 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, const Tables &T, fl
     if (disp && lane < npx) disp[(size_t)i * W + j0 + p0 + lane] = (float)res;
 }
 
-template <int C, int VIEW>
-__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, Tables T, float *__restrict__ vol,
+template <int C, int VIEW, bool FULL>
+__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, int D, Tables T, float *__restrict__ vol,
                                                   float *__restrict__ disp)
 {
-    cost_fast_body<C, VIEW>(H, W, T, vol, disp);
+    cost_fast_body<C, VIEW, FULL>(H, W, D, T, vol, disp);
 }
 
 // both views in one launch: blockIdx.z selects the view (no gap / tail between two launches)
-template <int C>
-__global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, Tables T, float *__restrict__ vol0,
+template <int C, bool FULL>
+__global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T, float *__restrict__ vol0,
                                                    float *__restrict__ vol1, float *__restrict__ disp0,
                                                    float *__restrict__ disp1)
 {
-    if (blockIdx.z == 0) cost_fast_body<C, 0>(H, W, T, vol0, disp0);
-    else cost_fast_body<C, 1>(H, W, T, vol1, disp1);
+    if (blockIdx.z == 0) cost_fast_body<C, 0, FULL>(H, W, D, T, vol0, disp0);
+    else cost_fast_body<C, 1, FULL>(H, W, D, T, vol1, disp1);
 }
 
-// generic WTA over an existing volume: one wave per pixel.
-template <int C>
+// WTA over an existing volume: one wave per pixel, lane owns C consecutive d (one vector load when
+// D == 64*C), DPP argmin.
+template <int C, bool FULL>
 __global__ void __launch_bounds__(NT) k_wta(const float *__restrict__ vol, int N, int D,
                                             float *__restrict__ disp)
 {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int p = blockIdx.x * (NT / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (p >= N) return;
-    const float *c = vol + (size_t)p * D;
-    float best = INFINITY; int bd = 0;
     const int dl = lane * C;
+    const float *c = vol + (size_t)p * D + dl;
+    float v[C];
+    if (FULL) {
+        const vecf<C> x = *reinterpret_cast<const vecf<C> *>(c);
 #pragma unroll
-    for (int k = 0; k < C; k++) {
-        const int d = dl + k;
-        if (d < D) {
-            const float v = c[d];
-            if (k == 0 || best > v) { best = v; bd = d; }
-        }
+        for (int k = 0; k < C; k++) v[k] = x.v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = (dl + k < D) ? c[k] : INFINITY;
     }
-    if (dl >= D) best = INFINITY;
+    float best = v[0]; int bd = dl;
+#pragma unroll
+    for (int k = 1; k < C; k++)
+        if ((FULL || dl + k < D) && best > v[k]) { best = v[k]; bd = dl + k; }
+    if (!FULL && dl >= D) best = INFINITY;
     const int wd = wave_argmin_first(best, bd);
     if (lane == 0) disp[p] = (float)wd;
 }
@@ -651,23 +675,21 @@ static void launch_cost(smt_adcensus *h, int view0, int nviews, float *d0, float
                        view0, h->vol[0], h->vol[1], d0, d1);
 }
 
-template <int C>
+template <int C, bool FULL>
 static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
 {
     dim3 grid((h->W + FTJ - 1) / FTJ, h->H);
-#ifndef SMT_SPLIT_VIEWS
     if (views == SMT_VIEW_BOTH) {
         dim3 g2(grid.x, grid.y, 2);
-        hipLaunchKernelGGL((k_cost_fast2<C>), g2, dim3(NT), 0, h->stream, h->H, h->W, h->T, h->vol[0],
+        hipLaunchKernelGGL((k_cost_fast2<C, FULL>), g2, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
                            h->vol[1], dL, dR);
         return;
     }
-#endif
     if (views & SMT_VIEW_LEFT)
-        hipLaunchKernelGGL((k_cost_fast<C, 0>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->T,
+        hipLaunchKernelGGL((k_cost_fast<C, 0, FULL>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
                            h->vol[0], dL);
     if (views & SMT_VIEW_RIGHT)
-        hipLaunchKernelGGL((k_cost_fast<C, 1>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->T,
+        hipLaunchKernelGGL((k_cost_fast<C, 1, FULL>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
                            h->vol[1], dR);
 }
 
@@ -703,16 +725,25 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
     const int C = (D + 63) / 64;
     const bool full = (D % 64) == 0;
-    switch (C * 2 + ((full && !h->force_generic) ? 1 : 0)) {
-    case 3: launch_fast<1>(h, views, dL, dR); break;
-    case 5: launch_fast<2>(h, views, dL, dR); break;
-    case 7: launch_fast<3>(h, views, dL, dR); break;
-    case 9: launch_fast<4>(h, views, dL, dR); break;
-    case 2: launch_cost<1, false>(h, view0, nviews, dL, dR); break;
-    case 4: launch_cost<2, false>(h, view0, nviews, dL, dR); break;
-    case 6: launch_cost<3, false>(h, view0, nviews, dL, dR); break;
-    case 8: launch_cost<4, false>(h, view0, nviews, dL, dR); break;
-    default: return SMT_ERR_ARG;
+    if (h->force_generic) {
+        switch (C) {                                       // the table-lookup kernel of the first version,
+        case 1: launch_cost<1, false>(h, view0, nviews, dL, dR); break;   // kept as an independent formulation
+        case 2: launch_cost<2, false>(h, view0, nviews, dL, dR); break;
+        case 3: launch_cost<3, false>(h, view0, nviews, dL, dR); break;
+        default: launch_cost<4, false>(h, view0, nviews, dL, dR); break;
+        }
+    } else {
+        switch (C * 2 + (full ? 1 : 0)) {
+        case 3: launch_fast<1, true>(h, views, dL, dR); break;
+        case 5: launch_fast<2, true>(h, views, dL, dR); break;
+        case 7: launch_fast<3, true>(h, views, dL, dR); break;
+        case 9: launch_fast<4, true>(h, views, dL, dR); break;
+        case 2: launch_fast<1, false>(h, views, dL, dR); break;
+        case 4: launch_fast<2, false>(h, views, dL, dR); break;
+        case 6: launch_fast<3, false>(h, views, dL, dR); break;
+        case 8: launch_fast<4, false>(h, views, dL, dR); break;
+        default: return SMT_ERR_ARG;
+        }
     }
     if (timed) { (void)hipEventRecord(ev[3], h->stream); h->n_timed++; }
     SMT_HIP(hipEventRecord(h->cost_done[set], h->stream));
@@ -813,12 +844,19 @@ SMT_API int smt_wta(const float *vol, int H, int W, int D, float *disp, void *st
     dim3 grid((N + 3) / 4);
     const int C = (D + 63) / 64;
     hipStream_t st = smt_stream(stream);
+    const bool full = (D == 64 * C);
+#define SMT_WTA(CC)                                                                                  \
+    do {                                                                                             \
+        if (full) hipLaunchKernelGGL((k_wta<CC, true>), grid, dim3(NT), 0, st, vol, N, D, disp);     \
+        else hipLaunchKernelGGL((k_wta<CC, false>), grid, dim3(NT), 0, st, vol, N, D, disp);         \
+    } while (0)
     switch (C) {
-    case 1: hipLaunchKernelGGL(k_wta<1>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
-    case 2: hipLaunchKernelGGL(k_wta<2>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
-    case 3: hipLaunchKernelGGL(k_wta<3>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
-    default: hipLaunchKernelGGL(k_wta<4>, grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    case 1: SMT_WTA(1); break;
+    case 2: SMT_WTA(2); break;
+    case 3: SMT_WTA(3); break;
+    default: SMT_WTA(4); break;
     }
+#undef SMT_WTA
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }

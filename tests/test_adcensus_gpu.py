@@ -50,8 +50,6 @@ CASES += [
 @pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("H,W,D,seed,noise", CASES)
 def test_adcensus_bit_exact(smt, O, H, W, D, seed, noise, generic):
-    if generic and D % 64:
-        pytest.skip("already the general kernel")
     L, R = O.synth_pair(H, W, D, seed, noise)
     vl, vr, dl, dr = _run(smt, L, R, D, generic=generic)
     ol = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
