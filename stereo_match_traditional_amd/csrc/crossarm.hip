@@ -25,6 +25,7 @@
 #include "smt_common.h"
 #include <limits.h>
 #include <new>
+#include <type_traits>
 
 namespace {
 
@@ -311,54 +312,40 @@ __global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__
     }
 }
 
-// ---- wave-private LDS aggregation (D == 64*C) -------------------------------------------------
-// One wave owns WP adjacent pixels.  Their rectangles overlap almost entirely, so the wave walks
-// the UNION of the WP rectangles in the reference's outer/inner order in segments of WR inner
-// positions, streams each segment once into a wave-private LDS ring with global_load_lds (no
-// VGPR staging, no workgroup barrier -- the only synchronisation is the wave's own counted
-// vmcnt), and every pixel whose rectangle contains the segment adds its part from LDS, in
-// order.  Global loads drop by the overlap factor (~5x for typical arms); the adds read LDS.
-// Rectangles that leave the plane (reference UB) take the per-pixel slow path.
-constexpr int WP = 8;             // pixels per wave
-constexpr int WR = 8;             // inner positions per segment
-constexpr int WNS = 3;            // ring slots per wave
-
-template <int C, int ORDER>
-__global__ void __launch_bounds__(NT) k_aggregate_wave(const float *__restrict__ vin, float *__restrict__ vout,
-                                                       int H, int W, const int *__restrict__ armL,
+// ---- register-level tap sharing: QP adjacent pixels per wave ----------------------------------
+// The wave walks the bounding box of its QP rectangles in the reference's outer/inner order, 64 box
+// positions at a time: every lane classifies one position (which of the QP rectangles contain it)
+// and computes its byte offset; a ballot keeps only positions that belong to at least one rectangle,
+// so each tap of the UNION is loaded exactly once and added -- in order -- to every pixel whose
+// rectangle contains it (wave-uniform branches).  For neighbouring pixels union/sum of areas is
+// ~0.5 (4 pixels), which is the saving on the texture path that bounds this stage.
+template <int C, int ORDER, bool FULL, int QP>
+__global__ void __launch_bounds__(NT) k_aggregate_quad(const float *__restrict__ vin, float *__restrict__ vout,
+                                                       int H, int W, int D, const int *__restrict__ armL,
                                                        const int *__restrict__ armR, const int *__restrict__ armT,
                                                        const int *__restrict__ armB, float *__restrict__ disp,
                                                        int *ub_flag, int SW)
 {
-    constexpr int D = 64 * C;
-    constexpr int RB = D * 4;                            // bytes per line
-    constexpr int SLOT = WR * D;                         // floats per slot
-    constexpr int NQ = (WR * RB) / 1024;                 // DMA instructions per segment (= 2*C)
-    extern __shared__ __attribute__((aligned(16))) float s_w[];        // [waves][WNS][WR][D]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *ring = s_w + (size_t)wv * WNS * SLOT;
     const int N = H * W;
-
-    // XCD-aware order as in k_aggregate_pipe; a wave takes WP consecutive pixels of a strip row
     int p0, nlive;
     {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int gpr = SW / (WP * (NT / 64));           // blocks per strip row
+        const int gpr = SW / (QP * (NT / 64));           // blocks per strip row
         const int gps = gpr * H;
         const int strip = xcd + 8 * (slot / gps);
         const int g = slot % gps;
-        const int row = g / gpr, col = strip * SW + ((g % gpr) * (NT / 64) + wv) * WP;
+        const int row = g / gpr, col = strip * SW + ((g % gpr) * (NT / 64) + wv) * QP;
         if (col >= W || strip * SW >= W) return;
         p0 = row * W + col;
-        nlive = min(WP, W - col);
+        nlive = min(QP, W - col);
     }
-    // rectangles relative to p0: pixel q covers outer [oa,ob] x inner [ia,ib]
-    int oa[WP], ob[WP], ia[WP], ib[WP], cnt[WP];
+    int oa[QP], ob[QP], ia[QP], ib[QP], cnt[QP];
     int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
     bool ub = false;
 #pragma unroll
-    for (int q = 0; q < WP; q++) {
+    for (int q = 0; q < QP; q++) {
         oa[q] = 1; ob[q] = 0; ia[q] = 1; ib[q] = 0; cnt[q] = 1;
         if (q < nlive) {
             const int p = p0 + q;
@@ -374,81 +361,102 @@ __global__ void __launch_bounds__(NT) k_aggregate_wave(const float *__restrict__
     }
     const int so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
     const int dl = lane * C;
-    float acc[WP][C];
+    float acc[QP][C];
 #pragma unroll
-    for (int q = 0; q < WP; q++)
+    for (int q = 0; q < QP; q++)
 #pragma unroll
         for (int k = 0; k < C; k++) acc[q][k] = 0.0f;
+    const char *base = (const char *)(vin + dl);
+
+    auto ld = [&](unsigned off, float (&x)[C]) {
+        const float *src = (const float *)(base + off);
+        if (FULL) {
+            const vecf<C> v = *reinterpret_cast<const vecf<C> *>(src);
+#pragma unroll
+            for (int k = 0; k < C; k++) x[k] = v.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++) x[k] = (dl + k < D) ? src[k] : 0.0f;
+        }
+    };
+
+    // acc[q] += x for every pixel q in the wave-uniform membership mask m: one 16-way switch instead
+    // of QP bit tests and branches per tap
+    auto add_bits = [&](auto mtag, auto basetag, const float (&x)[C]) {
+        constexpr unsigned M = decltype(mtag)::value;
+        constexpr int B = decltype(basetag)::value;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if ((M & (1u << q)) && B + q < QP) {
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[B + q < QP ? B + q : 0][c] = acc[B + q < QP ? B + q : 0][c] + x[c];
+            }
+    };
+    auto add_nibble = [&](unsigned m, auto basetag, const float (&x)[C]) {
+        switch (m) {
+#define SMT_CASE(V) case V: add_bits(std::integral_constant<unsigned, V>{}, basetag, x); break;
+            SMT_CASE(1) SMT_CASE(2) SMT_CASE(3) SMT_CASE(4) SMT_CASE(5) SMT_CASE(6) SMT_CASE(7) SMT_CASE(8)
+            SMT_CASE(9) SMT_CASE(10) SMT_CASE(11) SMT_CASE(12) SMT_CASE(13) SMT_CASE(14) SMT_CASE(15)
+#undef SMT_CASE
+        default: break;
+        }
+    };
+    auto add_masked = [&](unsigned m, const float (&x)[C]) {
+        add_nibble(m & 15u, std::integral_constant<int, 0>{}, x);
+        if (QP > 4) add_nibble(m >> 4, std::integral_constant<int, 4>{}, x);
+    };
 
     if (!ub) {
-        const int nch = (imax - imin + 1 + WR - 1) / WR;
-        const int nseg = (omax - omin + 1) * nch;
-        // per-lane position inside a segment for each of the NQ DMA instructions
-        int lrow[NQ], lbyte[NQ];
+        const int nIb = imax - imin + 1;
+        const int total = (omax - omin + 1) * nIb;
+        const float rI = 1.0f / (float)nIb;
+        for (int n0 = 0; n0 < total; n0 += 64) {
+            const int n = n0 + lane;
+            int o = (int)((float)n * rI);
+            int t = n - o * nIb;
+            if (t < 0) { o--; t += nIb; }
+            if (t >= nIb) { o++; t -= nIb; }
+            o += omin; t += imin;
+            unsigned mask = 0;
+            if (n < total) {
 #pragma unroll
-        for (int k = 0; k < NQ; k++) {
-            const int e = k * 1024 + lane * 16;
-            lrow[k] = e / RB;
-            lbyte[k] = e - lrow[k] * RB;
-        }
-        auto issue = [&](int seg) {
-            const int o = omin + seg / nch, n0 = imin + (seg % nch) * WR;
-            const int rows = min(WR, imax - n0 + 1);     // lines really needed; the rest re-read line 0
-            const int idx0 = p0 + o * so + n0 * si;
-            float *slot = ring + (seg % WNS) * SLOT;
-#pragma unroll
-            for (int k = 0; k < NQ; k++) {
-                const int r = lrow[k] < rows ? lrow[k] : 0;
-                // union-box positions that belong to no rectangle may lie outside the plane: clamp
-                // the source line (its data is never added)
-                int idx = idx0 + r * si;
-                idx = idx < 0 ? 0 : (idx > N - 1 ? N - 1 : idx);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)((const char *)vin + (size_t)idx * RB + lbyte[k]),
-                    (__attribute__((address_space(3))) void *)(slot + k * 256), 16, 0, 0);
+                for (int q = 0; q < QP; q++)
+                    mask |= (unsigned)(o >= oa[q] && o <= ob[q] && t >= ia[q] && t <= ib[q]) << q;
             }
-        };
+            const unsigned offs = (unsigned)(p0 + o * so + t * si) * (unsigned)(D * 4);
+            unsigned long long live = __ballot(mask != 0);
+            // full groups of AU union taps: indices, then all loads, then the in-order adds
+            while (__builtin_popcountll(live) >= AU) {
+                int u[AU];
+                float x[AU][C];
 #pragma unroll
-        for (int s = 0; s < WNS - 1; s++)
-            if (s < nseg) issue(s);
-        for (int seg = 0; seg < nseg; seg++) {
-            // the slot segment seg-1 used is free once its reads have returned
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (seg + WNS - 1 < nseg) {
-                issue(seg + WNS - 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * (WNS - 1)) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int k = 0; k < AU; k++) { u[k] = __builtin_ctzll(live); live &= live - 1; }
+#pragma unroll
+                for (int k = 0; k < AU; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
+#pragma unroll
+                for (int k = 0; k < AU; k++) add_masked((unsigned)__builtin_amdgcn_readlane((int)mask, u[k]), x[k]);
             }
-            const int o = omin + seg / nch, n0 = imin + (seg % nch) * WR;
-            const float *src = ring + (seg % WNS) * SLOT + dl;
-#pragma unroll
-            for (int q = 0; q < WP; q++) {
-                if (o >= oa[q] && o <= ob[q]) {
-                    const int a = max(n0, ia[q]) - n0, b = min(n0 + WR - 1, ib[q]) - n0;
-#pragma unroll
-                    for (int r = 0; r < WR; r++) {
-                        if (r >= a && r <= b) {
-#pragma unroll
-                            for (int k = 0; k < C; k++) acc[q][k] = acc[q][k] + src[r * D + k];
-                        }
-                    }
-                }
+            while (live) {
+                const int u = __builtin_ctzll(live);
+                live &= live - 1;
+                float x[C];
+                ld((unsigned)__builtin_amdgcn_readlane((int)offs, u), x);
+                add_masked((unsigned)__builtin_amdgcn_readlane((int)mask, u), x);
             }
         }
     } else {
-        // reference UB: per-pixel walk, out-of-plane taps contribute nothing
 #pragma unroll
-        for (int q = 0; q < WP; q++) {
+        for (int q = 0; q < QP; q++) {
             if (q >= nlive) continue;
             const int nO = ob[q] - oa[q] + 1, nI = ib[q] - ia[q] + 1;
             for (int o = 0; o < nO; o++)
                 for (int n = 0; n < nI; n++) {
                     const long idx = (long)p0 + (long)(oa[q] + o) * so + (long)(ia[q] + n) * si;
                     if (idx >= 0 && idx < N) {
-                        const vecf<C> v = *reinterpret_cast<const vecf<C> *>(vin + idx * D + dl);
+                        float x[C];
+                        ld((unsigned)idx * (unsigned)(D * 4), x);
 #pragma unroll
-                        for (int k = 0; k < C; k++) acc[q][k] = acc[q][k] + v.v[k];
+                        for (int c = 0; c < C; c++) acc[q][c] = acc[q][c] + x[c];
                     }
                 }
         }
@@ -456,18 +464,21 @@ __global__ void __launch_bounds__(NT) k_aggregate_wave(const float *__restrict__
     }
 
 #pragma unroll
-    for (int q = 0; q < WP; q++) {
+    for (int q = 0; q < QP; q++) {
         if (q >= nlive) continue;
         const float fc = (float)cnt[q];
-        vecf<C> o;
-        float best = 0.0f; int bk = 0;
+        float best = INFINITY; int bk = 0;
+        float *dst = vout + (size_t)(p0 + q) * D + dl;
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            o.v[k] = acc[q][k] / fc;
-            if (k == 0 || best > o.v[k]) { best = o.v[k]; bk = k; }
+            const float v = acc[q][k] / fc;
+            if (FULL || dl + k < D) {
+                dst[k] = v;
+                if (k == 0 || best > v) { best = v; bk = k; }
+            }
         }
-        *reinterpret_cast<vecf<C> *>(vout + (size_t)(p0 + q) * D + dl) = o;
         if (disp) {
+            if (!FULL && dl >= D) best = INFINITY;
             const int wd = wave_argmin_first(best, dl + bk);
             if (lane == 0) disp[p0 + q] = (float)wd;
         }
@@ -505,7 +516,7 @@ struct smt_crossarm {
     int *flip;     // 4 flip indices + 1 UB flag
     bool have_arms;
     int variant;         // aggregation kernel variant (test / tuning hook)
-    int strip_w;         // column-strip width of the XCD-aware pixel order (variant 0)
+    int strip_w;         // column-strip width of the XCD-aware pixel order (variants 0 and 2)
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -525,7 +536,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
-    h->H = H; h->W = W; h->D = D; h->strip_w = 64;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
@@ -587,33 +598,32 @@ SMT_API int smt_crossarm_arm_maps(smt_crossarm *h, int **l, int **r, int **t, in
     return SMT_OK;
 }
 
-template <int ORDER>
-static int launch_agg_wave(smt_crossarm *h, const float *vin, float *vout, float *disp)
+template <int ORDER, int QP>
+static void launch_agg_quad(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
-    const int C = h->D / 64;
     int SW = h->strip_w;
-    const int bw = WP * (NT / 64);                       // pixels per block along a strip row
+    const int bw = QP * (NT / 64);
     SW = ((SW + bw - 1) / bw) * bw;
     const int nstrips = (h->W + SW - 1) / SW;
     const int per_xcd = (nstrips + 7) / 8;
     dim3 grid((unsigned)(8 * per_xcd * (SW / bw) * h->H));
-    const size_t shm = (size_t)(NT / 64) * WNS * WR * h->D * 4;
+    const int C = (h->D + 63) / 64;
+    const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
-#define SMT_AGGW(CC)                                                                                       \
-    do {                                                                                                   \
-        auto kfn = k_aggregate_wave<CC, ORDER>;                                                            \
-        SMT_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        hipLaunchKernelGGL(kfn, grid, dim3(NT), shm, h->stream, vin, vout, h->H, h->W, h->arm[0], h->arm[1],  \
-                           h->arm[2], h->arm[3], disp, ub, SW);                                            \
-    } while (0)
-    switch (C) {
-    case 1: SMT_AGGW(1); break;
-    case 2: SMT_AGGW(2); break;
-    case 3: SMT_AGGW(3); break;
-    default: SMT_AGGW(4); break;
+#define SMT_AGGQ(CC, FF)                                                                                  \
+    hipLaunchKernelGGL((k_aggregate_quad<CC, ORDER, FF, QP>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW)
+    switch (C * 2 + (full ? 1 : 0)) {
+    case 2: SMT_AGGQ(1, false); break;
+    case 3: SMT_AGGQ(1, true); break;
+    case 4: SMT_AGGQ(2, false); break;
+    case 5: SMT_AGGQ(2, true); break;
+    case 6: SMT_AGGQ(3, false); break;
+    case 7: SMT_AGGQ(3, true); break;
+    case 8: SMT_AGGQ(4, false); break;
+    default: SMT_AGGQ(4, true); break;
     }
-#undef SMT_AGGW
-    return SMT_OK;
+#undef SMT_AGGQ
 }
 
 template <int ORDER>
@@ -665,16 +675,13 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 0 = pipelined walk (default), 1 = plain walk (any size, also the UB-safe reference
-    // form), 2 = wave-private LDS sharing (needs D % 64 == 0, else 0)
+    // variant: 0 = 4 adjacent pixels per wave sharing the taps of the union of their rectangles
+    // (default), 1 = plain one-pixel-per-wave walk (also the form used for volumes >= 4 GiB),
+    // 2 = pipelined one-pixel-per-wave walk.  0 and 2 address taps with 32-bit byte offsets.
     int variant = h->variant;
-    if (variant == 2 && (h->D % 64)) variant = 0;
-    // variant 0 addresses taps with 32-bit byte offsets
-    if (variant == 0 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
-    if (variant == 2) {
-        int rc = (order == 0) ? launch_agg_wave<0>(h, vin, vout, disp) : launch_agg_wave<1>(h, vin, vout, disp);
-        if (rc != SMT_OK) return rc;
-    } else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
+    if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
+    if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
+    else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;

@@ -55,7 +55,7 @@ def pipeline(H, W, D, seed, noise, reps):
         caL.set_variant(v)
         res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     caL.set_variant(0)
-    for sw in (16, 128):
+    for sw in (16, 32, 128):
         caL.set_strip_width(sw)
         res[f"aggregate_L_strip{sw}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     caL.set_strip_width(64)
