@@ -289,3 +289,36 @@ def test_config3_full_size_properties(smt):
     assert torch.equal(torch.isinf(d1), torch.isinf(d2))
     assert no1 + nm1 == int(torch.isinf(d1).sum())
     assert no2 + nm2 == no1 + nm1
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_cblsm_portrait_image(smt, O, variant):
+    """CBLSM-style arms have no stride bug, so portrait images are defined: arms + row-major
+    aggregation (costAggregationV5) on a 96x61 image, D not a multiple of 4."""
+    H, W, D = 96, 61, 22
+    img = smooth_img(H, W, 21)
+    vol = np.random.default_rng(2).random((H, W, D), dtype=np.float32)
+    arms = O.arms_all(img, 25, 6, 17, 34, chain=False, right_row_bug=False)
+    ref, oob = O.aggregate_rect(vol, arms, 1)
+    assert oob == 0
+    ca = smt.CrossArmAggregation().Initialize(H, W, 25, D, DEV, style="cblsm")
+    ca.set_variant(variant)
+    ca.ComputeArmLengths(T(img))
+    for g, r in zip(ca.arm_maps(), arms):
+        assert np.array_equal(g.cpu().numpy(), r)
+    out = torch.empty((H, W, D), device=DEV)
+    disp = torch.empty((H, W), device=DEV)
+    ca.costAggregationV5(T(vol), out, disp)
+    ca.status()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    assert np.array_equal(disp.cpu().numpy(), O.wta(ref))
+    ca.close()
+
+
+def test_adcensus_style_portrait_is_rejected(smt):
+    """With the reference's right-arm stride bug a portrait image makes it read outside the image."""
+    from stereo_match_traditional_amd import SmtError
+    ca = smt.CrossArmAggregation().Initialize(80, 50, 30, 8, DEV)
+    with pytest.raises(SmtError):
+        ca.ComputeArmLengths(torch.zeros((80, 50), dtype=torch.uint8, device=DEV))
+    ca.close()
