@@ -41,6 +41,10 @@ def _run(smt, L, R, D, sc=10.0, ss=30.0, generic=False):
 
 
 CASES += [
+    (6, 20, 1, 15, False),      # a single hypothesis
+    (5, 40, 255, 16, True),     # C=4 with one lane straddling D
+    (4, 3, 70, 17, False),      # narrower than the census window and than D
+    (3, 1, 4, 18, True),        # one column
     (7, 300, 64, 12, False),    # several workgroups per row + ragged tail (fast kernel: 128 px/WG)
     (6, 257, 192, 13, True),
     (5, 129, 256, 14, False),

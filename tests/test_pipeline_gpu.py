@@ -142,7 +142,8 @@ def test_cblsm_ad(smt, O):
         assert np.array_equal(bits(got), bits(O.cblsm_ad(L, R, D, v)))
 
 
-SCAN_CASES = [(20, 40, 16, 3), (12, 70, 64, 4), (9, 33, 100, 5), (10, 50, 192, 6), (7, 21, 256, 7), (3, 5, 8, 8)]
+SCAN_CASES = [(20, 40, 16, 3), (12, 70, 64, 4), (9, 33, 100, 5), (10, 50, 192, 6), (7, 21, 256, 7), (3, 5, 8, 8),
+              (1, 9, 5, 9), (9, 1, 5, 10), (2, 2, 1, 11), (1, 1, 3, 12)]   # single row / column / hypothesis / pixel
 
 
 @pytest.mark.parametrize("H,W,D,seed", SCAN_CASES)
