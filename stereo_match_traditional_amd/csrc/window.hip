@@ -215,11 +215,13 @@ __global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, con
             const int pa = __builtin_amdgcn_readlane(pa_l, c0 + cc);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const int pb = (word[k] >> (8 * cc)) & 0xff;
-                const double m2 = w * lut[abs(pb - cb[k]) * 32];
-                int e = abs(pa - pb);
-                e = e > T ? T : e;
-                sw[k] += m2;
+                const unsigned pb = (word[k] >> (8 * cc)) & 0xffu;
+                // |x - y| in one v_sad_u16 (operands < 256)
+                const double c1 = lut[__builtin_amdgcn_sad_u16(pb, (unsigned)cb[k], 0u) * 32];
+                unsigned e = __builtin_amdgcn_sad_u16((unsigned)pa, pb, 0u);
+                e = e > (unsigned)T ? (unsigned)T : e;
+                const double m2 = w * c1;
+                sw[k] = __builtin_fma(w, c1, sw[k]);
                 sv[k] = __builtin_fma(m2, (double)e, sv[k]);
             }
         }
