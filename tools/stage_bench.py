@@ -58,7 +58,7 @@ def pipeline(H, W, D, seed, noise, reps):
     for sw in (16, 32, 128):
         caL.set_strip_width(sw)
         res[f"aggregate_L_strip{sw}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
-    caL.set_strip_width(64)
+    caL.set_strip_width(16)
     res["aggregate_L_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     res["aggregate_R_ms"] = timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), max(1, reps // 4))
     caL.status()
