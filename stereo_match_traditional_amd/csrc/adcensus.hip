@@ -50,9 +50,11 @@ struct Tables {
 // Away from the left/right borders the extended tables equal the ordinary censuses:
 //   cenX_R[xr] == cenA_R[xr] for xr >= 3      (no neighbour column is clamped to 0)
 //   cenX_L[xl] == cenA_L[xl] for xl <= W-4    (no neighbour wraps to column 0, centre unclamped)
-// so k_prep computes the two ordinary censuses + mask once per pixel from LDS-staged rows and
+// so k_prep computes the two ordinary censuses + mask once per pixel from an LDS-staged 64x16 tile and
 // writes them to both places; k_prep_edges fills the 6 + 7 special columns per row.
-constexpr int PTW = 256;                                    // pixels per workgroup (one row segment)
+constexpr int PTW = 64;                                     // tile: 64 columns x 16 rows per workgroup
+constexpr int PTH = 16;
+constexpr int PNT = 256;                                    // each thread does one column of 4 rows
 
 __device__ __forceinline__ unsigned to_u8_checked(float a, bool &bad)
 {
@@ -61,59 +63,67 @@ __device__ __forceinline__ unsigned to_u8_checked(float a, bool &bad)
     return (unsigned)ia & 0xffu;
 }
 
-__global__ void __launch_bounds__(PTW) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
+__global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
                                               int H, int W, Tables T)
 {
-    __shared__ uint8_t sL[9][PTW + 8];
-    __shared__ uint8_t sR[9][PTW + 8];
-    const int i = blockIdx.y;
+    constexpr int SR = PTH + 8, SC = PTW + 6;               // staged rows / columns (4-row, 3-column halo)
+    __shared__ uint8_t sL[SR][SC + 2];
+    __shared__ uint8_t sR[SR][SC + 2];
+    const int i0 = blockIdx.y * PTH;
     const int x0 = blockIdx.x * PTW;
     const int tid = threadIdx.x;
-    // stage rows i-4..i+4, columns x0-3..x0+PTW+2 straight from the float images (coordinates
-    // clamped; out-of-image taps are masked); this also is the float -> u8 conversion + domain check
+    // stage the tile + halo straight from the float images (coordinates clamped; out-of-image taps
+    // are masked); this also is the float -> u8 conversion + domain check
     bool bad = false;
-    for (int e = tid; e < 9 * (PTW + 6); e += PTW) {
-        const int r = e / (PTW + 6), c = e - r * (PTW + 6);
-        int ii = i + r - 4, jj = x0 + c - 3;
+    for (int e = tid; e < SR * SC; e += PNT) {
+        const int r = e / SC, c = e - r * SC;
+        int ii = i0 + r - 4, jj = x0 + c - 3;
         ii = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
         jj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
         sL[r][c] = (uint8_t)to_u8_checked(Lf[(size_t)ii * W + jj], bad);
         sR[r][c] = (uint8_t)to_u8_checked(Rf[(size_t)ii * W + jj], bad);
     }
     if (__syncthreads_or(bad) && tid == 0) atomicOr(T.flag, 1);
-    const int x = x0 + tid;
+    const int col = tid & (PTW - 1);
+    const int x = x0 + col;
     if (x >= W) return;
-    T.u8[0][(size_t)i * W + x] = sL[4][tid + 3];
-    T.u8[1][(size_t)i * W + x] = sR[4][tid + 3];
-    // Branch-free: every staged byte is readable (coordinates were clamped at staging), the raw
-    // comparison bits are masked afterwards with the tap-validity word.  Bits are assembled in two
-    // 32-bit halves with compile-time positions (tap t -> bit 62-t).
-    const unsigned lc = sL[4][tid + 3], rc = sR[4][tid + 3];
-    unsigned clh = 0, cll = 0, crh = 0, crl = 0, mh = 0, ml = 0;
+#pragma unroll 1
+    for (int rr = 0; rr < PTH / (PNT / PTW); rr++) {
+        const int row = (tid / PTW) * (PTH / (PNT / PTW)) + rr;
+        const int i = i0 + row;
+        if (i >= H) break;
+        T.u8[0][(size_t)i * W + x] = sL[row + 4][col + 3];
+        T.u8[1][(size_t)i * W + x] = sR[row + 4][col + 3];
+        // Branch-free: every staged byte is readable, the raw comparison bits are masked afterwards with
+        // the tap-validity word.  Bits are assembled in two 32-bit halves with compile-time positions
+        // (tap t -> bit 62-t).
+        const unsigned lc = sL[row + 4][col + 3], rc = sR[row + 4][col + 3];
+        unsigned clh = 0, cll = 0, crh = 0, crl = 0, mh = 0, ml = 0;
 #pragma unroll
-    for (int r = 0; r < 9; r++) {
-        const int ii = i + r - 4;
-        const unsigned rv = (ii >= 0 && ii < H) ? 1u : 0u;
+        for (int r = 0; r < 9; r++) {
+            const int ii = i + r - 4;
+            const unsigned rv = (ii >= 0 && ii < H) ? 1u : 0u;
 #pragma unroll
-        for (int c = 0; c < 7; c++) {
-            const int pos = 62 - (r * 7 + c);
-            const int jj = x + c - 3;
-            const unsigned v = rv & ((jj >= 0 && jj < W) ? 1u : 0u);
-            const unsigned bl = (lc > (unsigned)sL[r][tid + c]) ? 1u : 0u;
-            const unsigned br = (rc > (unsigned)sR[r][tid + c]) ? 1u : 0u;
-            if (pos >= 32) { clh |= bl << (pos - 32); crh |= br << (pos - 32); mh |= v << (pos - 32); }
-            else           { cll |= bl << pos;        crl |= br << pos;        ml |= v << pos; }
+            for (int c = 0; c < 7; c++) {
+                const int pos = 62 - (r * 7 + c);
+                const int jj = x + c - 3;
+                const unsigned v = rv & ((jj >= 0 && jj < W) ? 1u : 0u);
+                const unsigned bl = (lc > (unsigned)sL[row + r][col + c]) ? 1u : 0u;
+                const unsigned br = (rc > (unsigned)sR[row + r][col + c]) ? 1u : 0u;
+                if (pos >= 32) { clh |= bl << (pos - 32); crh |= br << (pos - 32); mh |= v << (pos - 32); }
+                else           { cll |= bl << pos;        crl |= br << pos;        ml |= v << pos; }
+            }
         }
+        const uint64_t m = ((uint64_t)mh << 32) | ml;
+        const uint64_t cl = (((uint64_t)clh << 32) | cll) & m;
+        const uint64_t cr = (((uint64_t)crh << 32) | crl) & m;
+        const size_t p = (size_t)i * W + x;
+        T.cenA[0][p] = cl;
+        T.cenA[1][p] = cr;
+        T.mask[p] = m;
+        if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cr;      // cenX_R index = xr + 3
+        if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cl;      // cenX_L index = xl
     }
-    const uint64_t m = ((uint64_t)mh << 32) | ml;
-    const uint64_t cl = (((uint64_t)clh << 32) | cll) & m;
-    const uint64_t cr = (((uint64_t)crh << 32) | crl) & m;
-    const size_t p = (size_t)i * W + x;
-    T.cenA[0][p] = cl;
-    T.cenA[1][p] = cr;
-    T.mask[p] = m;
-    if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cr;      // cenX_R index = xr + 3
-    if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cl;      // cenX_L index = xl
 }
 
 // the border columns of the extended tables: xr in [-3, 2] and xl in [W-3, W+3]
@@ -713,7 +723,7 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     hipStream_t ps = overlap ? h->prep_stream : h->stream;
     if (overlap && h->n_pairs >= 2) SMT_HIP(hipStreamWaitEvent(ps, h->cost_done[set], 0));
     if (timed) (void)hipEventRecord(ev[0], ps);
-    hipLaunchKernelGGL(k_prep, dim3((W + PTW - 1) / PTW, H), dim3(PTW), 0, ps, L, R, H, W, h->T);
+    hipLaunchKernelGGL(k_prep, dim3((W + PTW - 1) / PTW, (H + PTH - 1) / PTH), dim3(PNT), 0, ps, L, R, H, W, h->T);
     hipLaunchKernelGGL(k_prep_edges, dim3((H + 3) / 4), dim3(64), 0, ps, H, W, h->T);
     if (timed) (void)hipEventRecord(ev[1], ps);
     if (overlap) {
