@@ -323,3 +323,37 @@ def test_adcensus_style_portrait_is_rejected(smt):
     with pytest.raises(SmtError):
         ca.ComputeArmLengths(torch.zeros((80, 50), dtype=torch.uint8, device=DEV))
     ca.close()
+
+
+def test_config3_full_size_bands_vs_oracle(smt, O):
+    """configs[2] size (1920x1080, D=192), stage by stage against the oracle on bands:
+    - arms: the full maps (the oracle's sequential walk is cheap);
+    - AggregationVertical: rows 500..519 of the d-slice 0..7, oracle fed with the band 460..559 of the
+      GPU's own cost volume and the arm maps (rectangles of the compared rows stay inside the band);
+    - ScanLineLeftRight: rows are independent, two rows of both passes."""
+    from stereo_match_traditional_amd import synth
+    H, W, D = 1080, 1920, 192
+    L, R = synth.synth_pair(H, W, D, 3)
+    Lf, Rf = T(L.astype(np.float32)), T(R.astype(np.float32))
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+    adc.ComputeBoth()
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.ComputeArmLengths(T(L))
+    arms_ref = O.arms_all(L)
+    arms = [a.cpu().numpy() for a in ca.arm_maps()]
+    for g, r in zip(arms, arms_ref):
+        assert np.array_equal(g, r)
+    agg = torch.empty((H, W, D), device=DEV)
+    ca.AggregationVertical(adc.GetPtrLeft(), agg)
+    ca.status()
+    a, b = 460, 560
+    sub = np.ascontiguousarray(adc.GetPtrLeft()[a:b, :, :8].cpu().numpy())
+    ref, _ = O.aggregate_rect(sub, [m[a:b] for m in arms], 0)
+    got = agg[500:520, :, :8].cpu().numpy()
+    assert np.array_equal(bits(got), bits(ref[40:60]))
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
+    for which in ("left", "right"):
+        out = so.ScanPass(agg, Lf, which)
+        rows = slice(700, 702)
+        ref = O.scan_pass(agg[rows].cpu().numpy(), L[rows].astype(np.float32), 10, 150, which)
+        assert np.array_equal(bits(out[rows].cpu().numpy()), bits(ref)), which
