@@ -632,7 +632,10 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     float lut[320];
     for (int k = 0; k < 256; k++) lut[k] = 1.0f - expf(-((float)k / sigmaC));
     for (int k = 0; k < 64; k++) lut[256 + k] = 1.0f - expf(-((float)k / sigmaS));
+    // the reference's `new float[size*dispRange]()` value-initialises the volumes (AD-Census.h:341-342):
+    // GetPtrLeft/Right before the first Compute* reads zeros
     if (hipMemcpy(h->TS[0].lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->vol[0], 0, V * 4) != hipSuccess || hipMemset(h->vol[1], 0, V * 4) != hipSuccess ||
         hipMemset(h->TS[0].flag, 0, 4) != hipSuccess) {
         smt_adcensus_destroy(h);
         return SMT_ERR_HIP;
