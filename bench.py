@@ -44,9 +44,30 @@ def cpu_baseline(H, W, D, seed, rows=256):
     orc.wta(vr[i0:i1])
     dt = time.perf_counter() - t0
     hyp = rows * W * D
-    return {"value": round(hyp / dt / 1e6, 4), "unit": "Mdisp/s", "cores": 1, "kind": "port",
+    base = {"value": round(hyp / dt / 1e6, 4), "unit": "Mdisp/s", "cores": 1, "kind": "port",
             "sample": f"rows {i0}..{i1 - 1} of the {W}x{H} D={D} pair ({hyp / 1e6:.1f} M hypotheses, "
                       f"both views + WTA, {dt:.1f} s, gcc -O2, 1 thread)"}
+    # same loops, rows-parallel OpenMP build, all host cores (BASELINE.md plan, item 2) -- extra info
+    try:
+        import ctypes
+        omp = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsmt_oracle_omp.so"))
+        ncores = len(os.sched_getaffinity(0))
+        Lf = np.ascontiguousarray(L, np.float32)
+        Rf = np.ascontiguousarray(R, np.float32)
+        out = np.zeros((H, W, D), np.float32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        # one untimed row first: starts the OpenMP thread pool and touches the pages
+        omp.orc_adcensus_view(p(Lf), p(Rf), H, W, D, ctypes.c_float(10.0), ctypes.c_float(30.0), 0, i0, i0 + 1, p(out))
+        t0 = time.perf_counter()
+        for view in (0, 1):
+            omp.orc_adcensus_view(p(Lf), p(Rf), H, W, D, ctypes.c_float(10.0), ctypes.c_float(30.0), view, i0, i1, p(out))
+            d = np.empty((rows, W), np.float32)
+            omp.orc_wta(p(out[i0:i1]), rows, W, D, p(d))
+        dt2 = time.perf_counter() - t0
+        base["all_cores"] = {"value": round(hyp / dt2 / 1e6, 3), "cores": ncores, "seconds": round(dt2, 2)}
+    except OSError:
+        pass
+    return base
 
 
 def pmc_traffic(workload):

@@ -24,7 +24,9 @@
  * complexity (e.g. the 9x7 census is rebuilt for every (i,j,d)) because this file is
  * also what bench.py times as the CPU baseline ("port").
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math).  The same file built with
+ * -fopenmp (libsmt_oracle_omp.so) parallelises the AD-Census stage over rows for the all-core CPU
+ * baseline; the default build ignores the pragmas (the reference's AD-CensusV1 has no OpenMP).
  */
 #include <math.h>
 #include <stddef.h>
@@ -78,6 +80,7 @@ ORC_API void orc_synth_pair(int H, int W, int D, uint32_t seed, int noise,
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_ad_left(const float *L, const float *R, int H, int W, int D, float *out)
 {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             float lv = L[i * W + j];
@@ -91,6 +94,7 @@ ORC_API void orc_ad_left(const float *L, const float *R, int H, int W, int D, fl
 
 ORC_API void orc_ad_right(const float *L, const float *R, int H, int W, int D, float *out)
 {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             float rv = R[i * W + j];
@@ -118,6 +122,7 @@ static int orc_popcount64_loop(uint64_t x)
 ORC_API void orc_census_left(const float *L, const float *R, int H, int W, int D,
                              int i0, int i1, float *out)
 {
+#pragma omp parallel for schedule(static)      /* only in libsmt_oracle_omp.so (all-core baseline) */
     for (int i = i0; i < i1; i++)
         for (int j = 0; j < W; j++) {
             float lc = L[i * W + j];
@@ -144,6 +149,7 @@ ORC_API void orc_census_left(const float *L, const float *R, int H, int W, int D
 ORC_API void orc_census_right(const float *L, const float *R, int H, int W, int D,
                               int i0, int i1, float *out)
 {
+#pragma omp parallel for schedule(static)
     for (int i = i0; i < i1; i++)
         for (int j = 0; j < W; j++) {
             float rc = R[i * W + j];
@@ -175,6 +181,7 @@ ORC_API void orc_census_right(const float *L, const float *R, int H, int W, int 
 ORC_API void orc_fuse(const float *ad, const float *census, size_t n, float sigmaC,
                       float sigmaS, float *cost)
 {
+#pragma omp parallel for schedule(static)
     for (size_t k = 0; k < n; k++) {
         float a = 1.0f - expf(-(ad[k] / sigmaC));
         float c = 1.0f - expf(-(census[k] / sigmaS));
@@ -220,6 +227,7 @@ ORC_API int orc_adcensus_view(const float *L, const float *R, int H, int W, int 
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_wta(const float *vol, int H, int W, int D, float *disp)
 {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++) {
             const float *c = vol + ((size_t)i * W + j) * D;
