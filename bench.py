@@ -50,8 +50,10 @@ def cpu_baseline(H, W, D, seed, rows=256):
     # same loops, rows-parallel OpenMP build, all host cores (BASELINE.md plan, item 2) -- extra info
     try:
         import ctypes
+        # a one-GPU box owns a 16-CPU share of the host whatever the affinity mask says
+        ncores = min(len(os.sched_getaffinity(0)), 16)
+        os.environ["OMP_NUM_THREADS"] = str(ncores)
         omp = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsmt_oracle_omp.so"))
-        ncores = len(os.sched_getaffinity(0))
         Lf = np.ascontiguousarray(L, np.float32)
         Rf = np.ascontiguousarray(R, np.float32)
         out = np.zeros((H, W, D), np.float32)

@@ -63,7 +63,6 @@ struct ScanArgs {
     float *disp;         // fused WTA of the accumulated volume (last pass) or null
     int H, W, D;
     float p1, p2;
-    int accumulate;      // out = out + path instead of out = path
 };
 
 template <int C> struct vecf;
@@ -336,7 +335,7 @@ static int scan_pass(smt_scanline *h, const ScanArgs &a, int pass, int mode)
 SMT_API int smt_scanline_pass(smt_scanline *h, const float *vin, const float *gray, int pass, float *vout)
 {
     if (!h || !vin || !gray || !vout || vin == vout || pass < 0 || pass > 3) return SMT_ERR_ARG;
-    ScanArgs a{vin, gray, vout, nullptr, nullptr, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2, 0};
+    ScanArgs a{vin, gray, vout, nullptr, nullptr, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2};
     return scan_pass(h, a, pass, 0);
 }
 
@@ -347,7 +346,7 @@ SMT_API int smt_scanline_run(smt_scanline *h, const float *vin, const float *gra
         int rc = smt_malloc((void **)&h->scratch, (size_t)h->H * h->W * h->D * 4);
         if (rc != SMT_OK) return rc;
     }
-    ScanArgs a{vin, gray, vout, h->scratch, h->scratch, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2, 0};
+    ScanArgs a{vin, gray, vout, h->scratch, h->scratch, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2};
     switch ((h->D + 63) / 64) {                                            // left -> vout, right -> scratch
     case 1: launch_lr<1>(h, a); break;
     case 2: launch_lr<2>(h, a); break;

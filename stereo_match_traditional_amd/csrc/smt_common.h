@@ -43,13 +43,6 @@ __device__ __forceinline__ float wave_min_f32(float v)
     for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, WAVE));
     return v;
 }
-__device__ __forceinline__ float wave_max_f32(float v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
-    return v;
-}
-
 // ---- DPP wave reductions (gfx9 row_bcast forms; all 64 lanes must be active) ------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v)
