@@ -200,3 +200,40 @@ def test_full_size_row_bands_vs_oracle(smt, O, H, W, D, seed):
             assert np.array_equal(got.view(np.uint32), ref[i0:i1].view(np.uint32)), (view, i0)
             assert np.array_equal(disp[i0:i1].cpu().numpy(), O.wta(ref[i0:i1])), (view, i0)
     adc.close()
+
+
+def test_non_default_stream_and_single_views(smt, O):
+    """Work issued on a side stream (the handle follows torch's current stream) and each view on its own
+    with a fused WTA; results must not depend on the stream or on which views were requested."""
+    from stereo_match_traditional_amd._lib import check, lib
+    from stereo_match_traditional_amd.api import _ptr
+    H, W, D = 20, 150, 128
+    L, R = O.synth_pair(H, W, D, 77)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream()
+    ol, orr = O.adcensus_view(L, R, D, 10.0, 30.0, 0), O.adcensus_view(L, R, D, 10.0, 30.0, 1)
+    with torch.cuda.stream(side):
+        Lf = torch.from_numpy(L.astype(np.float32)).to(dev, non_blocking=True)
+        Rf = torch.from_numpy(R.astype(np.float32)).to(dev, non_blocking=True)
+        adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+        dl = torch.empty((H, W), device=dev)
+        dr = torch.empty((H, W), device=dev)
+        adc._bind_stream()
+        check(lib().smt_adcensus_compute(adc._h, _ptr(Lf), _ptr(Rf), smt.VIEW_RIGHT, None, _ptr(dr)), "right only")
+        check(lib().smt_adcensus_compute(adc._h, _ptr(Lf), _ptr(Rf), smt.VIEW_LEFT, _ptr(dl), None), "left only")
+        vl, vr = adc.GetPtrLeft().clone(), adc.GetPtrRight().clone()
+    side.synchronize()
+    adc.status()
+    assert np.array_equal(vl.cpu().numpy().view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(vr.cpu().numpy().view(np.uint32), orr.view(np.uint32))
+    assert np.array_equal(dl.cpu().numpy(), O.wta(ol)) and np.array_equal(dr.cpu().numpy(), O.wta(orr))
+    adc.close()
+
+
+def test_volumes_start_zeroed_like_the_reference(smt):
+    """AD-Census.h:341-342 value-initialises the volumes: GetPtr* before any Compute* reads zeros."""
+    dev = torch.device("cuda:0")
+    z = torch.zeros((6, 40), device=dev)
+    adc = smt.AD_Census().Initialize(z, z, 64, 6, 40, 10.0, 30.0)
+    assert float(adc.GetPtrLeft().abs().max()) == 0.0 and float(adc.GetPtrRight().abs().max()) == 0.0
+    adc.close()
