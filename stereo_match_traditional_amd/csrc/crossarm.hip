@@ -485,6 +485,261 @@ __global__ void __launch_bounds__(NT) k_aggregate_quad(const float *__restrict__
     }
 }
 
+// ---- 8 or 16 pixels per wave, branch-free membership -----------------------------------------------
+// Same union walk as k_aggregate_quad with twice the sharing (union/sum of areas ~0.27 for 8 adjacent
+// pixels vs ~0.40 for 4).  The per-tap switch is what made 8 pixels slower there; here every union
+// tap is added to ALL 8 accumulators as fma(x, f, acc) with f = 1.0f for member pixels and 0.0f for
+// the others:  fma(x, 1, acc) is the reference's acc + x (one rounding of the exact sum) and
+// fma(x, 0, acc) == acc bit for bit for every finite x (acc starts at +0 and a sum that began at +0
+// is never -0, so adding +-0 leaves it unchanged).  The flags of a tap are one row of a 256 x 8
+// table in constant memory, fetched with the wave-uniform membership mask as one s_load_dwordx8, and
+// two pixels share each v_pk_fma_f32: 12 packed FMAs per tap for D = 192, below the texture path's
+// ~16 cycles per tap.  A non-finite x would turn fma(x, 0, acc) into NaN for non-members; every
+// pixel whose result holds a NaN is therefore recomputed with the plain in-order walk, which is the
+// reference's answer in every case (including a genuine NaN).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef int i3v __attribute__((ext_vector_type(3)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+constexpr int MEMBER_TAB_FLOATS = 256 * 8;   // row m: 8 floats, 1.0f where bit q of m is set
+
+// Buffer loads (SGPR resource + VGPR lane offset + SGPR tap offset).  Elements are converted with
+// __int_as_float: __builtin_bit_cast(float, v.y) on a vector element reads element 0 with this clang.
+__device__ __forceinline__ int buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0);
+}
+__device__ __forceinline__ i2v buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+{
+    return __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0);
+}
+__device__ __forceinline__ i3v buf_ld3(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+{
+    return __builtin_amdgcn_raw_buffer_load_b96(r, vo, so, 0);
+}
+__device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+}
+
+// One wave owns a block of QR rows x 8 columns of pixels (QR = 1: 8 pixels, QR = 2: 16 pixels; pixel
+// q = r*8 + c).  Lane q keeps pixel q's rectangle (box coordinates relative to the block's top-left
+// pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
+// box positions, so no rectangle lives in SGPRs across the tap loop.
+template <int C, int ORDER, bool FULL, int QR>
+__global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+                                                        int H, int W, int D, const int *__restrict__ armL,
+                                                        const int *__restrict__ armR, const int *__restrict__ armT,
+                                                        const int *__restrict__ armB, float *__restrict__ disp,
+                                                        int *ub_flag, int SW, const float *__restrict__ member)
+{
+    constexpr int QC = 8, NPIX = QC * QR;
+    constexpr int G = (QR == 1) ? 8 : 4;                 // union taps loaded per group
+    constexpr int BIAS = 16384;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = H * W;
+    int p0, ncol, nrow;
+    {
+        // XCD x = blockIdx%8 owns the column strips x, x+8, ... of width SW; a workgroup covers
+        // wx*8 columns by wy*QR rows (wx*wy = 4 waves), so narrow strips stack the waves vertically.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int wx = min(NT / 64, SW / QC), wy = (NT / 64) / wx;
+        const int gpr = SW / (QC * wx);
+        const int nband = (H + wy * QR - 1) / (wy * QR);
+        const int gps = gpr * nband;
+        const int strip = xcd + 8 * (slot / gps);
+        const int g = slot % gps;
+        const int row = ((g / gpr) * wy + wv / wx) * QR;
+        const int col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
+        if (row >= H || col >= W) return;
+        p0 = row * W + col;
+        ncol = min(QC, W - col);
+        nrow = min(QR, H - row);
+    }
+    const int so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
+    // lane q: rectangle of pixel q as outer [oa, ob] x inner [ia, ib]; empty for pixels off the image
+    int my_oa = 1, my_ob = 0, my_ia = 1, my_ib = 0;
+    bool my_ub = false;
+    {
+        const int r = lane >> 3, c = lane & 7;
+        if (lane < NPIX && r < nrow && c < ncol) {
+            const int p = p0 + r * W + c;
+            const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
+            if (ORDER == 0) { my_oa = c - Ll; my_ob = c + Rr; my_ia = r - up; my_ib = r + dn; }
+            else            { my_oa = r - up; my_ob = r + dn; my_ia = c - Ll; my_ib = c + Rr; }
+            my_ub = (p - Ll - up * W < 0) || ((long)p + Rr + (long)dn * W >= N);
+        }
+    }
+    const bool ub = __ballot(my_ub) != 0;
+    int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
+#pragma unroll
+    for (int q = 0; q < NPIX; q++) {
+        if ((q >> 3) < nrow && (q & 7) < ncol) {
+            omin = min(omin, __builtin_amdgcn_readlane(my_oa, q)); omax = max(omax, __builtin_amdgcn_readlane(my_ob, q));
+            imin = min(imin, __builtin_amdgcn_readlane(my_ia, q)); imax = max(imax, __builtin_amdgcn_readlane(my_ib, q));
+        }
+    }
+    unsigned pk_o = (unsigned)(my_oa + BIAS) | ((unsigned)(my_ob + BIAS) << 16);
+    unsigned pk_i = (unsigned)(my_ia + BIAS) | ((unsigned)(my_ib + BIAS) << 16);
+
+    const int dl = lane * C;
+    f2 acc[NPIX / 2][C];
+#pragma unroll
+    for (int j = 0; j < NPIX / 2; j++)
+#pragma unroll
+        for (int k = 0; k < C; k++) acc[j][k] = f2{0.0f, 0.0f};
+    const unsigned lane_off = (unsigned)dl * 4u;
+    // taps are fetched as buffer loads: wave-uniform byte offset of the tap in an SGPR, the lane's
+    // disparity offset in a VGPR, no per-tap address arithmetic (volume < 4 GiB, checked by the host)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)vin, 0, (int)((unsigned)N * (unsigned)(D * 4)), 0x00020000);
+    auto ld = [&](unsigned off, float (&x)[C]) {
+        if (FULL) {
+            if (C == 1) x[0] = __int_as_float(buf_ld1(rsrc, lane_off, off));
+            else if (C == 2) {
+                const i2v v = buf_ld2(rsrc, lane_off, off);
+                x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y);
+            } else if (C == 3) {
+                const i3v v = buf_ld3(rsrc, lane_off, off);
+                x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y);
+                x[C > 2 ? 2 : 0] = __int_as_float(v.z);
+            } else {
+                const i4v v = buf_ld4(rsrc, lane_off, off);
+                x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y);
+                x[C > 2 ? 2 : 0] = __int_as_float(v.z); x[C > 3 ? 3 : 0] = __int_as_float(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+                x[k] = (dl + k < D) ? __int_as_float(buf_ld1(rsrc, lane_off + 4u * k, off)) : 0.0f;
+        }
+    };
+    // acc[q] = fma(x, member(q) ? 1 : 0, acc[q]) for all pixels, two per v_pk_fma_f32
+    auto add_flagged = [&](unsigned m, const float (&x)[C]) {
+#pragma unroll
+        for (int h = 0; h < QR; h++) {
+            const float *f = member + ((m >> (8 * h)) & 255u) * 8u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f2 fl = f2{f[2 * j], f[2 * j + 1]};
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    acc[4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+            }
+        }
+    };
+
+    if (!ub) {
+        const int nIb = imax - imin + 1;
+        const int total = (omax - omin + 1) * nIb;
+        const float rI = 1.0f / (float)nIb;
+        for (int n0 = 0; n0 < total; n0 += 64) {
+            const int n = n0 + lane;
+            int o = (int)((float)n * rI);
+            int t = n - o * nIb;
+            if (t < 0) { o--; t += nIb; }
+            if (t >= nIb) { o++; t -= nIb; }
+            o += omin; t += imin;
+            asm volatile("" : "+v"(pk_o), "+v"(pk_i));   // keep the broadcasts below inside the loop
+            unsigned mask = 0;
+            {
+                const unsigned ob16 = (unsigned)(o + BIAS), tb16 = (unsigned)(t + BIAS);
+#pragma unroll
+                for (int q = 0; q < NPIX; q++) {
+                    const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q);
+                    const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
+                    const bool in = ob16 >= (bo & 0xffffu) && ob16 <= (bo >> 16) && tb16 >= (bi & 0xffffu) && tb16 <= (bi >> 16);
+                    mask |= (unsigned)in << q;
+                }
+                if (n >= total) mask = 0;
+            }
+            const unsigned offs = (unsigned)(p0 + o * so + t * si) * (unsigned)(D * 4);
+            unsigned long long live = __ballot(mask != 0);
+            // groups of union taps: indices, then all loads, then the in-order adds.  A short last
+            // group is padded with repeats of its last tap under an all-zero membership mask.
+            auto next = [&]() {
+                const int u = __builtin_ctzll(live);
+                asm("s_bitset0_b64 %0, %1" : "+s"(live) : "s"(u));
+                return u;
+            };
+            auto group = [&](auto gtag, auto padtag) {
+                constexpr int GG = decltype(gtag)::value;
+                constexpr bool PAD = decltype(padtag)::value;
+                int u[GG];
+                unsigned m[GG];
+                float x[GG][C];
+                int last = 0;
+#pragma unroll
+                for (int k = 0; k < GG; k++) {
+                    const bool valid = !PAD || live != 0;
+                    if (valid) last = next();
+                    u[k] = last;
+                    m[k] = valid ? (unsigned)__builtin_amdgcn_readlane((int)mask, last) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
+#pragma unroll
+                for (int k = 0; k < GG; k++) add_flagged(m[k], x[k]);
+            };
+            int cnt = __builtin_popcountll(live);
+            for (; cnt >= G; cnt -= G) group(std::integral_constant<int, G>{}, std::false_type{});
+            if (G == 8 && cnt > 4) group(std::integral_constant<int, G>{}, std::true_type{});
+            else if (cnt > 0) group(std::integral_constant<int, 4>{}, std::true_type{});
+        }
+    } else if (lane == 0) atomicOr(ub_flag, 1);
+
+    for (int q = 0; q < NPIX; q++) {
+        const int r = q >> 3, c = q & 7;
+        if (r >= nrow || c >= ncol) continue;
+        const int oa = __builtin_amdgcn_readlane(my_oa, q), ob = __builtin_amdgcn_readlane(my_ob, q);
+        const int ia = __builtin_amdgcn_readlane(my_ia, q), ib = __builtin_amdgcn_readlane(my_ib, q);
+        float a[C];
+        bool bad = ub;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            a[k] = 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < NPIX; qq++)            // static register selection
+                if (qq == q) a[k] = (qq & 1) ? acc[qq / 2][k].y : acc[qq / 2][k].x;
+            bad = bad || (a[k] != a[k]);
+        }
+        if (__ballot(bad)) {
+            // the reference's own walk for this pixel: rectangles that leave the plane (out-of-plane
+            // taps contribute nothing) and pixels the flag arithmetic may have polluted with a NaN
+#pragma unroll
+            for (int k = 0; k < C; k++) a[k] = 0.0f;
+            for (int o = oa; o <= ob; o++)
+                for (int t = ia; t <= ib; t++) {
+                    const long idx = (long)p0 + (long)o * so + (long)t * si;
+                    if (idx >= 0 && idx < N) {
+                        float x[C];
+                        ld((unsigned)idx * (unsigned)(D * 4), x);
+#pragma unroll
+                        for (int k = 0; k < C; k++) a[k] = a[k] + x[k];
+                    }
+                }
+        }
+        const float fc = (float)((ob - oa + 1) * (ib - ia + 1));
+        float best = INFINITY; int bk = 0;
+        const int p = p0 + r * W + c;
+        float *dst = vout + (size_t)p * D + dl;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const float v = a[k] / fc;
+            if (FULL || dl + k < D) {
+                dst[k] = v;
+                if (k == 0 || best > v) { best = v; bk = k; }
+            }
+        }
+        if (disp) {
+            if (!FULL && dl >= D) best = INFINITY;
+            const int wd = wave_argmin_first(best, dl + bk);
+            if (lane == 0) disp[p] = (float)wd;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_cblsm_ad(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R,
                                                  int H, int W, int D, int view, float *__restrict__ vol)
 {
@@ -517,6 +772,8 @@ struct smt_crossarm {
     bool have_arms;
     int variant;         // aggregation kernel variant (test / tuning hook)
     int strip_w;         // column-strip width of the XCD-aware pixel order (variants 0 and 2)
+    int strip_w8;        // the same for variant 3 (8 pixels per wave)
+    float *member;       // 256 x 8 membership flags for variant 3
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -536,14 +793,21 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
-    h->H = H; h->W = W; h->D = D; h->strip_w = 16;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 16; h->variant = 4;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
     for (int k = 0; k < 4 && rc == SMT_OK; k++) rc = smt_malloc((void **)&h->arm[k], (size_t)H * W * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->flip, 8 * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->member, MEMBER_TAB_FLOATS * 4);
     if (rc != SMT_OK) { smt_crossarm_destroy(h); return rc; }
     if (hipMemset(h->flip, 0, 32) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
+    {
+        float tab[MEMBER_TAB_FLOATS];
+        for (int m = 0; m < 256; m++)
+            for (int q = 0; q < 8; q++) tab[m * 8 + q] = ((m >> q) & 1) ? 1.0f : 0.0f;
+        if (hipMemcpy(h->member, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
+    }
     *out = h;
     return SMT_OK;
 }
@@ -553,6 +817,7 @@ SMT_API int smt_crossarm_destroy(smt_crossarm *h)
     if (!h) return SMT_ERR_ARG;
     for (int k = 0; k < 4; k++) (void)hipFree(h->arm[k]);
     (void)hipFree(h->flip);
+    (void)hipFree(h->member);
     delete h;
     return SMT_OK;
 }
@@ -626,6 +891,36 @@ static void launch_agg_quad(smt_crossarm *h, const float *vin, float *vout, floa
 #undef SMT_AGGQ
 }
 
+template <int ORDER, int QR>
+static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, float *disp)
+{
+    // strip width 8 / 16 / multiple of 32: the 4 waves of a workgroup sit 1x4, 2x2 or 4x1
+    int SW = h->strip_w8;
+    SW = SW <= 8 ? 8 : SW <= 16 ? 16 : ((SW + 31) / 32) * 32;
+    const int wx = SW / 8 < 4 ? SW / 8 : 4, wy = 4 / wx;
+    const int nstrips = (h->W + SW - 1) / SW;
+    const int per_xcd = (nstrips + 7) / 8;
+    const int nband = (h->H + wy * QR - 1) / (wy * QR);
+    dim3 grid((unsigned)(8 * per_xcd * (SW / (8 * wx)) * nband));
+    const int C = (h->D + 63) / 64;
+    const bool full = (h->D == 64 * C);
+    int *ub = h->flip + 4;
+#define SMT_AGGM(CC, FF)                                                                                  \
+    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member)
+    switch (C * 2 + (full ? 1 : 0)) {
+    case 2: SMT_AGGM(1, false); break;
+    case 3: SMT_AGGM(1, true); break;
+    case 4: SMT_AGGM(2, false); break;
+    case 5: SMT_AGGM(2, true); break;
+    case 6: SMT_AGGM(3, false); break;
+    case 7: SMT_AGGM(3, true); break;
+    case 8: SMT_AGGM(4, false); break;
+    default: SMT_AGGM(4, true); break;
+    }
+#undef SMT_AGGM
+}
+
 template <int ORDER>
 static void launch_agg_pipe(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
@@ -675,13 +970,17 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 0 = 4 adjacent pixels per wave sharing the taps of the union of their rectangles
-    // (default), 1 = plain one-pixel-per-wave walk (also the form used for volumes >= 4 GiB),
-    // 2 = pipelined one-pixel-per-wave walk.  0 and 2 address taps with 32-bit byte offsets.
+    // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, branch-free
+    // membership flags (default); 3 = the same with 1x8 pixels; 0 = 4 adjacent pixels per wave with a
+    // 16-way switch on the membership mask; 1 = plain one-pixel-per-wave walk (also the form used for
+    // volumes >= 4 GiB); 2 = pipelined one-pixel-per-wave walk.  All but 1 address taps with 32-bit
+    // byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
     if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
+    else if (variant == 3) { if (order == 0) launch_agg_multi<0, 1>(h, vin, vout, disp); else launch_agg_multi<1, 1>(h, vin, vout, disp); }
+    else if (variant == 4) { if (order == 0) launch_agg_multi<0, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -689,7 +988,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 2) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 4) return SMT_ERR_ARG;
     h->variant = variant;
     return SMT_OK;
 }
@@ -697,7 +996,7 @@ SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 SMT_API int smt_crossarm_set_strip_width(smt_crossarm *h, int w)
 {
     if (!h || w < 4 || (w & 3)) return SMT_ERR_ARG;
-    h->strip_w = w;
+    h->strip_w = w; h->strip_w8 = w;
     return SMT_OK;
 }
 

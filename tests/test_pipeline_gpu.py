@@ -95,7 +95,7 @@ AGG_CASES = [(72, 160, 16, "synth", 3), (64, 150, 64, "smooth", 5), (72, 160, 10
 AGG_CASES += [(70, 155, 60, "smooth", 12), (66, 149, 7, "synth", 13)]   # W % 16 != 0, D % 4 != 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("H,W,D,kind,seed", AGG_CASES)
 @pytest.mark.parametrize("order", [0, 1])
 def test_aggregation(smt, O, H, W, D, kind, seed, order, variant):
@@ -118,6 +118,38 @@ def test_aggregation(smt, O, H, W, D, kind, seed, order, variant):
     assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
     assert np.array_equal(disp.cpu().numpy(), O.wta(ref))
     ca.close()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_aggregation_non_finite_inputs(smt, O, order):
+    """inf / NaN in the input volume reach exactly the pixels whose rectangle holds them (the
+    8-pixel kernel recomputes any pixel its flag arithmetic may have polluted)."""
+    H, W, D = 60, 150, 64
+    img = _img(H, W, "smooth", 6, O)
+    rng = np.random.default_rng(6)
+    vol = rng.random((H, W, D), dtype=np.float32) * 2
+    for _ in range(12):
+        i, j, d = int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(0, D))
+        vol[i, j, d] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
+    vol[30, 70, :] = np.inf
+    arms = O.arms_all(img) if order == 0 else O.arms_all(img, 25, 6, 17, 34, chain=False, right_row_bug=False)
+    ref, oob = O.aggregate_rect(vol, arms, order)
+    assert oob == 0
+    outs = []
+    for variant in (1, 3, 4):
+        ca = smt.CrossArmAggregation().Initialize(H, W, 30 if order == 0 else 25, D, DEV,
+                                                  style="adcensus" if order == 0 else "cblsm")
+        ca.set_variant(variant)
+        ca.ComputeArmLengths(T(img))
+        out = torch.empty((H, W, D), device=DEV)
+        (ca.AggregationVertical if order == 0 else ca.costAggregationV5)(T(vol), out)
+        ca.status()
+        outs.append(out.cpu().numpy())
+        ca.close()
+    for o in outs:
+        assert np.array_equal(np.isnan(o), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.array_equal(bits(o)[ok], bits(ref)[ok])
 
 
 def test_aggregation_flags_reference_ub(smt, O):
@@ -292,7 +324,7 @@ def test_config3_full_size_properties(smt):
     assert no2 + nm2 == no1 + nm1
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_cblsm_portrait_image(smt, O, variant):
     """CBLSM-style arms have no stride bug, so portrait images are defined: arms + row-major
     aggregation (costAggregationV5) on a 96x61 image, D not a multiple of 4."""

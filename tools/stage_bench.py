@@ -51,11 +51,11 @@ def pipeline(H, W, D, seed, noise, reps):
     aggR = torch.empty((H, W, D), device=DEV)
     rL, rR, rT, rB = [a.float() for a in caR.arm_maps()]
     res["mean_rect_area_right"] = float(((rL + rR + 1) * (rT + rB + 1)).mean())
-    for v in (1, 2):
+    for v in (0, 1, 2, 3):
         caL.set_variant(v)
         res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
-    caL.set_variant(0)
-    for sw in (16, 32, 128):
+    caL.set_variant(4)
+    for sw in (8, 32, 64):
         caL.set_strip_width(sw)
         res[f"aggregate_L_strip{sw}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     caL.set_strip_width(16)
