@@ -689,40 +689,12 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
         }
     } else if (lane == 0) atomicOr(ub_flag, 1);
 
-    for (int q = 0; q < NPIX; q++) {
-        const int r = q >> 3, c = q & 7;
-        if (r >= nrow || c >= ncol) continue;
-        const int oa = __builtin_amdgcn_readlane(my_oa, q), ob = __builtin_amdgcn_readlane(my_ob, q);
-        const int ia = __builtin_amdgcn_readlane(my_ia, q), ib = __builtin_amdgcn_readlane(my_ib, q);
-        float a[C];
-        bool bad = ub;
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-            a[k] = 0.0f;
-#pragma unroll
-            for (int qq = 0; qq < NPIX; qq++)            // static register selection
-                if (qq == q) a[k] = (qq & 1) ? acc[qq / 2][k].y : acc[qq / 2][k].x;
-            bad = bad || (a[k] != a[k]);
-        }
-        if (__ballot(bad)) {
-            // the reference's own walk for this pixel: rectangles that leave the plane (out-of-plane
-            // taps contribute nothing) and pixels the flag arithmetic may have polluted with a NaN
-#pragma unroll
-            for (int k = 0; k < C; k++) a[k] = 0.0f;
-            for (int o = oa; o <= ob; o++)
-                for (int t = ia; t <= ib; t++) {
-                    const long idx = (long)p0 + (long)o * so + (long)t * si;
-                    if (idx >= 0 && idx < N) {
-                        float x[C];
-                        ld((unsigned)idx * (unsigned)(D * 4), x);
-#pragma unroll
-                        for (int k = 0; k < C; k++) a[k] = a[k] + x[k];
-                    }
-                }
-        }
-        const float fc = (float)((ob - oa + 1) * (ib - ia + 1));
+    // mean, store and fused WTA of one pixel
+    auto finish = [&](int q, const float (&a)[C]) {
+        const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q), bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
+        const float fc = (float)(((int)(bo >> 16) - (int)(bo & 0xffffu) + 1) * ((int)(bi >> 16) - (int)(bi & 0xffffu) + 1));
         float best = INFINITY; int bk = 0;
-        const int p = p0 + r * W + c;
+        const int p = p0 + (q >> 3) * W + (q & 7);
         float *dst = vout + (size_t)p * D + dl;
 #pragma unroll
         for (int k = 0; k < C; k++) {
@@ -737,6 +709,44 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
             const int wd = wave_argmin_first(best, dl + bk);
             if (lane == 0) disp[p] = (float)wd;
         }
+    };
+    // accumulators are read with static register numbers; pixels that need the plain walk (reference UB,
+    // or a NaN the flag arithmetic may have produced) are collected and handled by one rolled loop
+    unsigned redo = 0;
+#pragma unroll
+    for (int q = 0; q < NPIX; q++) {
+        if ((q >> 3) >= nrow || (q & 7) >= ncol) continue;
+        float a[C];
+        bool bad = ub;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            a[k] = (q & 1) ? acc[q / 2][k].y : acc[q / 2][k].x;
+            bad = bad || (a[k] != a[k]);
+        }
+        if (__ballot(bad)) { redo |= 1u << q; continue; }
+        finish(q, a);
+    }
+    while (redo) {
+        const int q = __builtin_ctz(redo);
+        redo &= redo - 1;
+        const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q), bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
+        const int oa = (int)(bo & 0xffffu) - BIAS, ob = (int)(bo >> 16) - BIAS;
+        const int ia = (int)(bi & 0xffffu) - BIAS, ib = (int)(bi >> 16) - BIAS;
+        // the reference's own walk for this pixel; out-of-plane taps contribute nothing
+        float a[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) a[k] = 0.0f;
+        for (int o = oa; o <= ob; o++)
+            for (int t = ia; t <= ib; t++) {
+                const long idx = (long)p0 + (long)o * so + (long)t * si;
+                if (idx >= 0 && idx < N) {
+                    float x[C];
+                    ld((unsigned)idx * (unsigned)(D * 4), x);
+#pragma unroll
+                    for (int k = 0; k < C; k++) a[k] = a[k] + x[k];
+                }
+            }
+        finish(q, a);
     }
 }
 
