@@ -180,9 +180,10 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising */
 /* Test / tuning hook: which aggregation kernel runs.  4 = 2x8 pixels per wave, every tap of the
- * union of their rectangles loaded once and added under branch-free membership flags (default),
- * 3 = the same with 1x8 pixels, 0 = four adjacent pixels per wave (mask switch), 1 = plain
- * one-pixel-per-wave walk, 2 = pipelined one-pixel-per-wave walk.  All produce identical bits. */
+ * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
+ * a member skipped (default), 5 = the same without the skip, 3 = 1x8 pixels without the skip,
+ * 0 = four adjacent pixels per wave (mask switch), 1 = plain one-pixel-per-wave walk,
+ * 2 = pipelined one-pixel-per-wave walk.  All produce identical bits. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps (all variants but 1;
  * variants 3 and 4 round it to 8, 16 or a multiple of 32). */

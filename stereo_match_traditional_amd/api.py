@@ -242,8 +242,8 @@ class CrossArmAggregation:
         wta(AggredCostVolume, disp)
 
     def set_variant(self, variant):
-        """4 = 2x8 pixels per wave sharing union taps (default), 3 = 1x8, 0 = four pixels per wave,
-        1 plain walk, 2 pipelined walk."""
+        """4 = 2x8 pixels per wave sharing union taps (default), 5 = same without group skip, 3 = 1x8,
+        0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
 
     def set_strip_width(self, w):

@@ -526,7 +526,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // q = r*8 + c).  Lane q keeps pixel q's rectangle (box coordinates relative to the block's top-left
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
-template <int C, int ORDER, bool FULL, int QR>
+template <int C, int ORDER, bool FULL, int QR, int SKIP>
 __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
@@ -615,17 +615,26 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
                 x[k] = (dl + k < D) ? __int_as_float(buf_ld1(rsrc, lane_off + 4u * k, off)) : 0.0f;
         }
     };
-    // acc[q] = fma(x, member(q) ? 1 : 0, acc[q]) for all pixels, two per v_pk_fma_f32
+    // acc[q] = fma(x, member(q) ? 1 : 0, acc[q]), two pixels per v_pk_fma_f32.  SKIP: a group of 4
+    // pixels none of which holds the tap is skipped by a wave-uniform branch (2.4 of 4 groups are live on
+    // average with 2x8 pixels; testing pairs instead costs more scalar work than it saves).
     auto add_flagged = [&](unsigned m, const float (&x)[C]) {
 #pragma unroll
         for (int h = 0; h < QR; h++) {
-            const float *f = member + ((m >> (8 * h)) & 255u) * 8u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
+            const unsigned mb = (m >> (8 * h)) & 255u;
+            const float *f = member + mb * 8u;
+            auto pair = [&](int j) {
                 const f2 fl = f2{f[2 * j], f[2 * j + 1]};
 #pragma unroll
                 for (int c = 0; c < C; c++)
                     acc[4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+            };
+            if (SKIP == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) pair(j);
+            } else {
+                if (mb & 0x0fu) { pair(0); pair(1); }
+                if (mb & 0xf0u) { pair(2); pair(3); }
             }
         }
     };
@@ -901,7 +910,7 @@ static void launch_agg_quad(smt_crossarm *h, const float *vin, float *vout, floa
 #undef SMT_AGGQ
 }
 
-template <int ORDER, int QR>
+template <int ORDER, int QR, int SKIP>
 static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
     // strip width 8 / 16 / multiple of 32: the 4 waves of a workgroup sit 1x4, 2x2 or 4x1
@@ -916,7 +925,7 @@ static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, flo
     const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
 #define SMT_AGGM(CC, FF)                                                                                  \
-    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
                        h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member)
     switch (C * 2 + (full ? 1 : 0)) {
     case 2: SMT_AGGM(1, false); break;
@@ -980,8 +989,9 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 {
     if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, branch-free
-    // membership flags (default); 3 = the same with 1x8 pixels; 0 = 4 adjacent pixels per wave with a
+    // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership
+    // flags, groups of 4 pixels without a member skipped (default); 5 = the same without the skip;
+    // 3 = 1x8 pixels, no skip; 0 = 4 adjacent pixels per wave with a
     // 16-way switch on the membership mask; 1 = plain one-pixel-per-wave walk (also the form used for
     // volumes >= 4 GiB); 2 = pipelined one-pixel-per-wave walk.  All but 1 address taps with 32-bit
     // byte offsets.
@@ -989,8 +999,9 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
     if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
-    else if (variant == 3) { if (order == 0) launch_agg_multi<0, 1>(h, vin, vout, disp); else launch_agg_multi<1, 1>(h, vin, vout, disp); }
-    else if (variant == 4) { if (order == 0) launch_agg_multi<0, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2>(h, vin, vout, disp); }
+    else if (variant == 3) { if (order == 0) launch_agg_multi<0, 1, 0>(h, vin, vout, disp); else launch_agg_multi<1, 1, 0>(h, vin, vout, disp); }
+    else if (variant == 4) { if (order == 0) launch_agg_multi<0, 2, 1>(h, vin, vout, disp); else launch_agg_multi<1, 2, 1>(h, vin, vout, disp); }
+    else if (variant == 5) { if (order == 0) launch_agg_multi<0, 2, 0>(h, vin, vout, disp); else launch_agg_multi<1, 2, 0>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -998,7 +1009,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 4) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 5) return SMT_ERR_ARG;
     h->variant = variant;
     return SMT_OK;
 }

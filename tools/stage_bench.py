@@ -51,7 +51,7 @@ def pipeline(H, W, D, seed, noise, reps):
     aggR = torch.empty((H, W, D), device=DEV)
     rL, rR, rT, rB = [a.float() for a in caR.arm_maps()]
     res["mean_rect_area_right"] = float(((rL + rR + 1) * (rT + rB + 1)).mean())
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 5):
         caL.set_variant(v)
         res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     caL.set_variant(4)
