@@ -348,6 +348,31 @@ def test_cblsm_portrait_image(smt, O, variant):
     ca.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_aggregation_out_of_plane_taps_contribute_nothing(smt, O, variant):
+    """Rectangles that leave the plane are reference UB (status says so); what every kernel
+    variant then computes is documented: the sum over the in-plane taps, divided by the full
+    rectangle area -- the oracle's own convention."""
+    from stereo_match_traditional_amd import SmtError
+    H, W, D = 24, 40, 64
+    img = np.full((H, W), 50, np.uint8)
+    vol = np.random.default_rng(variant).random((H, W, D), dtype=np.float32)
+    arms = O.arms_all(img)
+    ref, oob = O.aggregate_rect(vol, arms, 0)
+    assert oob > 0
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.set_variant(variant)
+    ca.ComputeArmLengths(T(img))
+    out = torch.empty((H, W, D), device=DEV)
+    disp = torch.empty((H, W), device=DEV)
+    ca.AggregationVertical(T(vol), out, disp)
+    with pytest.raises(SmtError):
+        ca.status()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    assert np.array_equal(disp.cpu().numpy(), O.wta(ref))
+    ca.close()
+
+
 def test_adcensus_style_portrait_is_rejected(smt):
     """With the reference's right-arm stride bug a portrait image makes it read outside the image."""
     from stereo_match_traditional_amd import SmtError
