@@ -233,6 +233,24 @@ int smt_lrcheck(float *dispL, const float *dispR, int H, int W, int gate, uint8_
 int smt_lrcheck_lists(const uint8_t *cls_host, int H, int W, int *occlusion_pairs, int *n_occ,
                       int *mismatch_pairs, int *n_mis);
 
+/* FillTheHole (AD-CensusV1/PostProcessing.h:156-248; same text in CBLSM/PostProcessing.h).
+ * In place on the DEVICE map disp (row*col floats).  The reference swaps the extents
+ * (`width = row`, `height = col`, :158-159) and this is reproduced: the buffer is addressed as
+ * `col` lines of `row` entries, and a hole is an entry equal to 65535.0f (:182, :212) -- not the
+ * +inf that LeftRightConsistency writes.  occ / mis: HOST arrays of (first, second) int pairs in
+ * list order, as LeftRightConsistency fills them.  Pass 0 gives each occlusion the second
+ * smallest of the first non-hole values met along 8 rays, pass 1 each mismatch their median,
+ * pass 2 (only when the mismatch list is not empty, :174) every remaining hole the median.
+ * The reference then leaves the third pass's pixel list in the caller's `mismatch` vector
+ * (:186): third (HOST, room for row*col pairs, may be NULL) and *n_third (may be NULL; -1 when
+ * the list was not replaced) return it.  SMT_ERR_REF_UB where the reference writes out of
+ * bounds: a listed pair outside the buffer (nothing is modified), or more third-pass holes than
+ * the mismatch list had entries (`fill_disps` is sized before the list is replaced, :177 vs
+ * :186; passes 0 and 1 have been applied by then, as in the reference).  Synchronising. */
+int smt_fill_the_hole(float *disp, int row, int col, int dispRange, const int *occlusion_pairs,
+                      int n_occ, const int *mismatch_pairs, int n_mis, int *third_pairs,
+                      int *n_third, void *stream);
+
 /* =====================================================================================
  * CrossAggregator (vendored ethan-li AD-Census)   replaces class CrossAggregator
  *                                     (CBLSM/cross_aggregator.{h,cpp})

@@ -303,3 +303,19 @@ def remove_speckles(d, diff, min_area, invalid_val):
     H, W = d.shape
     lib().orc_remove_speckles(_p(d), W, H, int(diff), C.c_uint(min_area), int(invalid_val))
     return d
+
+
+def fill_the_hole(disp, dispRange, occ, mis):
+    """FillTheHole on a [row][col] map.  Returns (filled map, third-pass list or None); raises
+    ValueError where the reference writes out of bounds."""
+    d = np.array(disp, np.float32, copy=True, order="C")
+    row, col = d.shape
+    occ = np.ascontiguousarray(np.asarray(occ, np.int32).reshape(-1, 2))
+    mis = np.ascontiguousarray(np.asarray(mis, np.int32).reshape(-1, 2))
+    third = np.empty((row * col, 2), np.int32)
+    nt = C.c_int(-1)
+    rc = lib().orc_fill_the_hole(_p(d), row, col, int(dispRange), _p(occ), len(occ), _p(mis), len(mis),
+                                 _p(third), C.byref(nt))
+    if rc != 0:
+        raise ValueError("reference behaviour undefined (out-of-bounds write in FillTheHole)")
+    return d, (third[:nt.value].copy() if nt.value >= 0 else None)

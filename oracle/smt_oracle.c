@@ -918,6 +918,78 @@ ORC_API void orc_remove_speckles(float *d, int W, int H, int diff, unsigned min_
     free(visited); free(vec);
 }
 
+/* FillTheHole                                             PostProcessing.h:156-248
+ * In place on disp (row*col floats).  The reference swaps the extents (`width = row`, `height =
+ * col`, :158-159): the buffer is read as `col` lines of `row` entries.  occ / mis: (first, second)
+ * pairs in list order.  Pass 0 fills the occlusion list (second smallest of the first valid values
+ * found along 8 rays, :227-233), pass 1 the mismatch list (median, :235-237), pass 2 every entry
+ * that still equals 65535 -- and replaces the caller's mismatch list by those (:186), returned in
+ * third / *n_third (capacity row*col pairs).  Every write of a pass happens after all its reads
+ * (:240-245).  Returns 0, or -1 where the reference itself writes out of bounds: a listed pair
+ * outside the buffer, or more third-pass holes than the mismatch list had entries (`fill_disps` is
+ * sized before the list is replaced, :180 vs :186). */
+static int flt_cmp(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+ORC_API int orc_fill_the_hole(float *disp, int row, int col, int dispRange, const int *occ, int n_occ,
+                              const int *mis, int n_mis, int *third, int *n_third)
+{
+    const int width = row, height = col;                                      /* :158-159 */
+    const float pi = 3.1415926f;
+    const float angle1[8] = {pi, 3 * pi / 4, pi / 2, pi / 4, 0, 7 * pi / 4, 3 * pi / 2, 5 * pi / 4};
+    const float angle2[8] = {pi, 5 * pi / 4, 3 * pi / 2, 7 * pi / 4, 0, pi / 4, pi / 2, 3 * pi / 4};
+    const float *angle = angle1;                                              /* sticky across passes, :166 */
+    const int max_search_length = (int)(1.0 * dispRange);                     /* :168 */
+    const long n = (long)row * col;
+    if (n_third) *n_third = -1;                                               /* -1: list not replaced */
+    for (int k = 0; k < 3; k++) {
+        const int *trg = (k == 0) ? occ : mis;
+        int nt = (k == 0) ? n_occ : n_mis;
+        if (nt == 0) continue;                                                /* :174-176 */
+        const int cap = nt;                                                   /* fill_disps(trg.size()), :177 */
+        int *inv = NULL;
+        if (k == 2) {                                                         /* :179-187 */
+            inv = (int *)malloc((size_t)n * 2 * sizeof(int));
+            int c = 0;
+            for (int i = 0; i < height; i++)
+                for (int j = 0; j < width; j++)
+                    if (disp[i * width + j] == 65535.0f) { inv[2 * c] = i; inv[2 * c + 1] = j; c++; }
+            trg = inv; nt = c;
+            if (third) { memcpy(third, inv, (size_t)c * 2 * sizeof(int)); }
+            if (n_third) *n_third = c;
+            if (nt > cap) { free(inv); return -1; }
+        }
+        float *fill = (float *)calloc((size_t)(cap > 0 ? cap : 1), sizeof(float));
+        for (int t = 0; t < nt; t++) {
+            const int y = trg[2 * t], x = trg[2 * t + 1];
+            const long at = (long)y * width + x;
+            if (at < 0 || at >= n) { free(fill); free(inv); return -1; }
+            if (y == height / 2) angle = angle2;                              /* :195-197 */
+            float got[8]; int ng = 0;
+            for (int s = 0; s < 8; s++) {
+                const float ang = angle[s];
+                const float sina = sinf(ang), cosa = cosf(ang);               /* sin(float) is the float overload, :203-204 */
+                for (int m = 1; m < max_search_length; m++) {
+                    const long yy = lroundf((float)y + (float)m * sina);      /* float arithmetic, :206-207 */
+                    const long xx = lroundf((float)x + (float)m * cosa);
+                    if (yy < 0 || yy >= height || xx < 0 || xx >= width) break;
+                    const float d = disp[yy * width + xx];
+                    if (d != 65535.0f) { got[ng++] = d; break; }
+                }
+            }
+            if (ng == 0) continue;                                            /* fill stays 0, :218-220 */
+            qsort(got, (size_t)ng, sizeof(float), flt_cmp);
+            if (k == 0) fill[t] = ng > 1 ? got[1] : got[0];
+            else fill[t] = got[ng / 2];
+        }
+        for (int t = 0; t < nt; t++) disp[(long)trg[2 * t] * width + trg[2 * t + 1]] = fill[t];   /* :240-245 */
+        free(fill); free(inv);
+    }
+    return 0;
+}
+
 /* FNV-1a 64 over raw bytes: fixture hashes */
 ORC_API uint64_t orc_fnv1a(const void *p, size_t n)
 {

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
-__all__ = ["AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
+__all__ = ["FillTheHole", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
@@ -359,6 +359,24 @@ def LeftRightConsistency(col, row, gate, leftDisp, rightDisp, want_lists=False):
     check(lib().smt_lrcheck_lists(ch.ctypes.data_as(C.c_void_p), row, col, occ.ctypes.data_as(C.c_void_p),
                                   C.byref(no), mis.ctypes.data_as(C.c_void_p), C.byref(nm)), "smt_lrcheck_lists")
     return cls, n[0], n[1], occ[:no.value], mis[:nm.value]
+
+
+def FillTheHole(row, col, dispRange, dispLeft, occlusion, mismatch):
+    """PostProcessing.h:156-248, in place on the device map dispLeft ([row][col] float32; the
+    reference's internal width/height swap is reproduced).  occlusion / mismatch: (first, second)
+    pairs ([n, 2] int arrays or lists of pairs) in list order.  Returns the mismatch list as the
+    reference leaves it: the third pass's pixels when that pass ran, else the input list."""
+    import numpy as np
+    _dev(dispLeft, torch.float32, (row, col), "dispLeft")
+    occ = np.ascontiguousarray(np.asarray(occlusion, np.int32).reshape(-1, 2))
+    mis = np.ascontiguousarray(np.asarray(mismatch, np.int32).reshape(-1, 2))
+    third = np.empty((row * col, 2), np.int32)
+    nt = C.c_int(-1)
+    check(lib().smt_fill_the_hole(_ptr(dispLeft), row, col, int(dispRange), occ.ctypes.data_as(C.c_void_p),
+                                  len(occ), mis.ctypes.data_as(C.c_void_p), len(mis),
+                                  third.ctypes.data_as(C.c_void_p), C.byref(nt), current_stream_ptr()),
+          "smt_fill_the_hole")
+    return third[:nt.value].copy() if nt.value >= 0 else mis
 
 
 # ======================================================================================

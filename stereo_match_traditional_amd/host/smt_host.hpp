@@ -214,6 +214,27 @@ inline void LeftRightConsistency(int col, int row, int gate, float *leftDisp, fl
     for (int k = 0; k < nm; k++) mismatch.emplace_back(m[2 * k], m[2 * k + 1]);
 }
 
+// ------------------------------------------------------------------ PostProcessing.h:156
+// Same signature and side effects as the reference, the replaced `mismatch` list included (:186).
+inline void FillTheHole(const int row, const int col, const int dispRange, float *dispLeft,
+                        std::vector<std::pair<int, int>> &occlusion, std::vector<std::pair<int, int>> &mismatch)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<float> d(n);
+    d.upload(dispLeft);
+    std::vector<int> o(2 * occlusion.size()), m(2 * mismatch.size()), third(2 * n);
+    for (size_t k = 0; k < occlusion.size(); k++) { o[2 * k] = occlusion[k].first; o[2 * k + 1] = occlusion[k].second; }
+    for (size_t k = 0; k < mismatch.size(); k++) { m[2 * k] = mismatch[k].first; m[2 * k + 1] = mismatch[k].second; }
+    int nt = -1;
+    check(smt_fill_the_hole(d.get(), row, col, dispRange, o.data(), (int)occlusion.size(), m.data(),
+                            (int)mismatch.size(), third.data(), &nt, nullptr), "smt_fill_the_hole");
+    d.download(dispLeft);
+    if (nt >= 0) {
+        mismatch.clear();
+        for (int k = 0; k < nt; k++) mismatch.emplace_back(third[2 * k], third[2 * k + 1]);
+    }
+}
+
 // ------------------------------------------------------------------ cross_aggregator.h:27-113
 struct CrossArm { uint8_t left, right, top, bottom; };
 

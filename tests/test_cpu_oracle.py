@@ -442,3 +442,88 @@ def test_asw_a11_numpy_equals_oracle(O):
                 srt = np.sort(cv)
                 if srt[1] - srt[0] > 1e-5:
                     assert disp[i, j] == int(np.argmin(cv))
+
+
+def _py_fill_the_hole(disp, dispRange, occ, mis):
+    """Independent restatement of FillTheHole (PostProcessing.h:156-248) in plain Python: lists
+    walked in order, one mutable `angle`, writes after reads, the width/height swap."""
+    import math
+    d = np.array(disp, np.float32).reshape(-1).copy()
+    row, col = disp.shape
+    width, height = row, col
+    f32 = np.float32
+    pi = f32(3.1415926)
+    a1 = [pi, f32(3) * pi / f32(4), pi / f32(2), pi / f32(4), f32(0), f32(7) * pi / f32(4), f32(3) * pi / f32(2), f32(5) * pi / f32(4)]
+    a2 = [pi, f32(5) * pi / f32(4), f32(3) * pi / f32(2), f32(7) * pi / f32(4), f32(0), pi / f32(4), pi / f32(2), f32(3) * pi / f32(4)]
+    angle = a1
+    mis = [tuple(p) for p in mis]
+    occ = [tuple(p) for p in occ]
+    replaced = None
+
+    def lround(v):                       # float argument, half away from zero
+        v = float(v)
+        return int(math.floor(v + 0.5)) if v >= 0 else -int(math.floor(-v + 0.5))
+
+    for k in range(3):
+        trg = occ if k == 0 else mis
+        if not trg:
+            continue
+        cap = len(trg)
+        if k == 2:
+            trg = [(i, j) for i in range(height) for j in range(width) if d[i * width + j] == 65535]
+            mis = replaced = trg
+            assert len(trg) <= cap, "reference UB"
+        fill = [f32(0)] * len(trg)
+        for n, (y, x) in enumerate(trg):
+            if y == height // 2:
+                angle = a2
+            got = []
+            for s in range(8):
+                sina = np.sin(angle[s], dtype=np.float32)
+                cosa = np.cos(angle[s], dtype=np.float32)
+                for m in range(1, int(1.0 * dispRange)):
+                    yy = lround(f32(y) + f32(m) * sina)
+                    xx = lround(f32(x) + f32(m) * cosa)
+                    if yy < 0 or yy >= height or xx < 0 or xx >= width:
+                        break
+                    v = d[yy * width + xx]
+                    if v != 65535:
+                        got.append(v)
+                        break
+            if not got:
+                continue
+            got.sort()
+            fill[n] = (got[1] if len(got) > 1 else got[0]) if k == 0 else got[len(got) // 2]
+        for n, (y, x) in enumerate(trg):
+            d[y * width + x] = fill[n]
+    return d.reshape(row, col), replaced
+
+
+@pytest.mark.parametrize("row,col,seed", [(24, 24, 0), (20, 31, 1), (18, 40, 2)])
+def test_fill_the_hole_python_restatement_equals_oracle(O, row, col, seed):
+    """numpy's float32 sin/cos and glibc's sinf/cosf agree on these 16 angles (checked here too)."""
+    rng = np.random.default_rng(seed)
+    D = 16
+    d = rng.integers(0, D, (row, col)).astype(np.float32)
+    holes = rng.random((row, col)) < 0.15
+    d[holes] = 65535
+    d[rng.random((row, col)) < 0.03] = np.inf            # what LeftRightConsistency leaves behind
+    n = row * col
+
+    def pairs(k):
+        flat = rng.integers(0, n, k)
+        # (first, second) with first*row + second inside the buffer; first < col keeps it a line index
+        return np.stack([flat // row, flat % row], 1).astype(np.int32)
+    occ = pairs(30)
+    mis = np.concatenate([pairs(int(holes.sum()) + 5), occ[:3]])      # includes duplicates
+    mis[7, 0] = col // 2                                              # the angle switch, mid-list
+    ref, third = O.fill_the_hole(d, D, occ, mis)
+    got, third_py = _py_fill_the_hole(d, D, occ, mis)
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    assert third is not None and [tuple(p) for p in third] == third_py
+    # no mismatch list -> no third pass (:174): holes survive
+    ref2, third2 = O.fill_the_hole(d, D, occ, np.empty((0, 2), np.int32))
+    assert third2 is None and (ref2 == 65535).sum() > 0
+    # more holes than mismatch entries: the reference overruns fill_disps
+    with pytest.raises(ValueError):
+        O.fill_the_hole(d, D, occ, mis[:3])
