@@ -193,6 +193,17 @@ int smt_crossarm_set_strip_width(smt_crossarm *h, int width);
 int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int view, float *vol,
                  void *stream);
 
+/* CBLSM.h:65-236 chooseArmLengthLeft / Right / Up / Down (dir 0 / 1 / 2 / 3): per-hypothesis arm
+ * lengths, int32 [H][W][D], from the two views' arm maps (int32 [H][W], e.g. smt_crossarm_arm_maps
+ * of a left-image and a right-image handle).  own_arm = ArmLL / ArmLR / ArmLUp / ArmLDown;
+ * other_vertical_arm = ArmRUp / ArmRDown for dir 2 / 3 (ignored for 0 / 1, may be NULL).  The
+ * reference's call sites are commented out (CBLSM.cpp:108-111); the up / down forms read the right
+ * view's arms at row i -/+ k for k <= own_arm, so own_arm must stay inside the image, as the arm
+ * kernels guarantee. */
+int smt_cblsm_choose_arm_length(int dir, const int *own_arm, const int *other_vertical_arm,
+                                const int *armRL, const int *armRR, int H, int W, int D,
+                                int *arm_volume, void *stream);
+
 /* =====================================================================================
  * Scanline optimiser                  replaces class ScanlineOptimizer
  *                                     (AD-CensusV1/ScanlineOptimizer.h)

@@ -319,3 +319,14 @@ def fill_the_hole(disp, dispRange, occ, mis):
     if rc != 0:
         raise ValueError("reference behaviour undefined (out-of-bounds write in FillTheHole)")
     return d, (third[:nt.value].copy() if nt.value >= 0 else None)
+
+
+def choose_arm_length(dirn, own, vert, RL, RR, D):
+    """chooseArmLength{Left,Right,Up,Down} (dirn 0..3) -> int32 [row][col][D]."""
+    own = _c(own, np.int32); RL = _c(RL, np.int32); RR = _c(RR, np.int32)
+    vert = _c(vert, np.int32) if vert is not None else None
+    row, col = own.shape
+    vol = np.empty((row, col, D), np.int32)
+    lib().orc_choose_arm_length(int(dirn), _p(own), _p(vert) if vert is not None else None, _p(RL), _p(RR),
+                                row, col, int(D), _p(vol))
+    return vol

@@ -990,6 +990,57 @@ ORC_API int orc_fill_the_hole(float *disp, int row, int col, int dispRange, cons
     return 0;
 }
 
+/* chooseArmLengthLeft / Right / Up / Down                  CBLSM.h:65-236
+ * dir 0..3; own = ArmLL / ArmLR / ArmLUp / ArmLDown, vert = ArmRUp / ArmRDown (dir 2 / 3). */
+ORC_API void orc_choose_arm_length(int dir, const int *own, const int *vert, const int *RL, const int *RR,
+                                   int row, int col, int D, int *vol)
+{
+    for (int i = 0; i < row; ++i)
+        for (int j = 0; j < col; ++j)
+            for (int d = 0; d < D; d++) {
+                int save = 0;
+                const size_t p = (size_t)i * col + j;
+                if (dir == 0) {
+                    int LL = own[p], rl = RL[p], rr = RR[p];
+                    if ((j - d < j - rl) || (j + d > j + rr)) { save = 0; }                    /* :76-82 */
+                    else
+                        for (int a = 1; a <= LL; a++) {
+                            if (((j - a - d) >= (j - rl)) && ((j - a - d) <= (j + rr))) save++;  /* :87-88 */
+                            else break;
+                        }
+                } else if (dir == 1) {
+                    int LR = own[p], rl = RL[p], rr = RR[p];
+                    if ((j - d < j - rl) || (j - d > j + rr)) { save = 0; }                    /* :123-129 */
+                    else
+                        for (int a = 1; a <= LR; a++) {
+                            if ((j + a - d >= j - rl) && (j + a - d < j + rr)) save++;         /* :134-135 */
+                            else break;
+                        }
+                } else if (dir == 2) {
+                    int LUp = own[p], RUp = vert[p];
+                    for (int up = 1; up <= LUp; up++) {                                        /* :164-185 */
+                        int pr = i - up;
+                        int pl = RL[(size_t)pr * col + j], prr = RR[(size_t)pr * col + j];
+                        if (pr >= (i - RUp)) {
+                            if (j - d < 0) break;
+                            if (((j - d) < (j + prr)) && ((j - d) > (j - pl))) save++;
+                        } else { save = 0; break; }
+                    }
+                } else {
+                    int LDown = own[p], RDown = vert[p];
+                    for (int down = 1; down <= LDown; down++) {                                /* :208-229 */
+                        int pr = i + down;
+                        int pl = RL[(size_t)pr * col + j], prr = RR[(size_t)pr * col + j];
+                        if (pr <= i + RDown) {
+                            if (j - d < 0) { save = 0; break; }
+                            if ((j - d <= j + prr) && (j - d >= j - pl)) save++;
+                        } else break;
+                    }
+                }
+                vol[p * D + d] = save;
+            }
+}
+
 /* FNV-1a 64 over raw bytes: fixture hashes */
 ORC_API uint64_t orc_fnv1a(const void *p, size_t n)
 {

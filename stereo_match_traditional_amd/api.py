@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
-__all__ = ["FillTheHole", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
+__all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
@@ -274,6 +274,39 @@ def cblsm_ComputeAD(L, R, dispRange, view=VIEW_LEFT, out=None):
     check(lib().smt_cblsm_ad(_ptr(L), _ptr(R), H, W, dispRange, view, _ptr(out), current_stream_ptr()),
           "smt_cblsm_ad")
     return out
+
+
+def _choose_arm(dirn, own, vert, ArmRL, ArmRR, dispRange, Armvolume, row, col):
+    for a in (own, vert, ArmRL, ArmRR):
+        if a is not None:
+            _dev(a, torch.int32, (row, col), "arm map")
+    if Armvolume is None:
+        Armvolume = torch.empty((row, col, dispRange), dtype=torch.int32, device=own.device)
+    _dev(Armvolume, torch.int32, (row, col, dispRange), "Armvolume")
+    check(lib().smt_cblsm_choose_arm_length(dirn, _ptr(own), _ptr(vert) if vert is not None else None, _ptr(ArmRL),
+                                            _ptr(ArmRR), row, col, int(dispRange), _ptr(Armvolume),
+                                            current_stream_ptr()), "smt_cblsm_choose_arm_length")
+    return Armvolume
+
+
+def chooseArmLengthLeft(ArmLL, ArmLR, ArmRL, ArmRR, dispRange, Armvolume, row, col):
+    """CBLSM.h:65-102 (argument order of the reference; ArmLR is unused there too)."""
+    return _choose_arm(0, ArmLL, None, ArmRL, ArmRR, dispRange, Armvolume, row, col)
+
+
+def chooseArmLengthRight(ArmLL, ArmLR, ArmRL, ArmRR, dispRange, Armvolume, row, col):
+    """CBLSM.h:104-147."""
+    return _choose_arm(1, ArmLR, None, ArmRL, ArmRR, dispRange, Armvolume, row, col)
+
+
+def chooseArmLengthUp(ArmLUp, ArmLDown, ArmRUp, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col):
+    """CBLSM.h:151-192."""
+    return _choose_arm(2, ArmLUp, ArmRUp, ArmRL, ArmRR, dispRange, Armvolume, row, col)
+
+
+def chooseArmLengthDown(ArmLUp, ArmLDown, ArmRUp, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col):
+    """CBLSM.h:195-236."""
+    return _choose_arm(3, ArmLDown, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col)
 
 
 # ======================================================================================

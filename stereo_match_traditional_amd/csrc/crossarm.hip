@@ -780,6 +780,58 @@ __global__ void __launch_bounds__(NT) k_cblsm_ad(const uint8_t *__restrict__ L, 
     vol[k] = (float)abs(a - b);
 }
 
+// CBLSM.h:65-236 chooseArmLength{Left,Right,Up,Down}: per-hypothesis arm lengths from the two
+// views' arm maps (experiments whose call sites are commented out, CBLSM.cpp:108-111).  One thread
+// per (i, j, d); the loops are the reference's, conditions in the reference's order.
+__global__ void __launch_bounds__(NT) k_choose_arm(int dir, const int *__restrict__ own, const int *__restrict__ vert,
+                                                   const int *__restrict__ RL, const int *__restrict__ RR, int H, int W,
+                                                   int D, int *__restrict__ out)
+{
+    const size_t k = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t V = (size_t)H * W * D;
+    if (k >= V) return;
+    const int d = (int)(k % D);
+    const size_t p = k / D;
+    const int j = (int)(p % W), i = (int)(p / W);
+    int save = 0;
+    if (dir == 0) {                                            // :65-102
+        const int LL = own[p], rl = RL[p], rr = RR[p];
+        if (!((j - d < j - rl) || (j + d > j + rr)))
+            for (int a = 1; a <= LL; a++) {
+                if (((j - a - d) >= (j - rl)) && ((j - a - d) <= (j + rr))) save++;
+                else break;
+            }
+    } else if (dir == 1) {                                     // :104-147
+        const int LR = own[p], rl = RL[p], rr = RR[p];
+        if (!((j - d < j - rl) || (j - d > j + rr)))
+            for (int a = 1; a <= LR; a++) {
+                if ((j + a - d >= j - rl) && (j + a - d < j + rr)) save++;
+                else break;
+            }
+    } else if (dir == 2) {                                     // :151-192
+        const int LUp = own[p], RUp = vert[p];
+        for (int up = 1; up <= LUp; up++) {
+            const int pr = i - up;
+            const int pl = RL[(size_t)pr * W + j], prr = RR[(size_t)pr * W + j];
+            if (pr >= i - RUp) {
+                if (j - d < 0) break;
+                if (((j - d) < (j + prr)) && ((j - d) > (j - pl))) save++;
+            } else { save = 0; break; }
+        }
+    } else {                                                   // :195-236
+        const int LDown = own[p], RDown = vert[p];
+        for (int dn = 1; dn <= LDown; dn++) {
+            const int pr = i + dn;
+            const int pl = RL[(size_t)pr * W + j], prr = RR[(size_t)pr * W + j];
+            if (pr <= i + RDown) {
+                if (j - d < 0) { save = 0; break; }
+                if ((j - d <= j + prr) && (j - d >= j - pl)) save++;
+            } else break;
+        }
+    }
+    out[k] = save;
+}
+
 }  // namespace
 
 struct smt_crossarm {
@@ -1038,6 +1090,20 @@ SMT_API int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D
     const size_t V = (size_t)H * W * D;
     hipLaunchKernelGGL(k_cblsm_ad, dim3((unsigned)((V + NT - 1) / NT)), dim3(NT), 0, smt_stream(stream), L, R,
                        H, W, D, view == SMT_VIEW_LEFT ? 0 : 1, vol);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_cblsm_choose_arm_length(int dir, const int *own_arm, const int *other_vertical_arm,
+                                        const int *armRL, const int *armRR, int H, int W, int D, int *arm_volume,
+                                        void *stream)
+{
+    if (dir < 0 || dir > 3 || !own_arm || !armRL || !armRR || !arm_volume || H <= 0 || W <= 0 || D <= 0 ||
+        (dir >= 2 && !other_vertical_arm))
+        return SMT_ERR_ARG;
+    const size_t V = (size_t)H * W * D;
+    hipLaunchKernelGGL(k_choose_arm, dim3((unsigned)((V + NT - 1) / NT)), dim3(NT), 0, smt_stream(stream), dir, own_arm,
+                       other_vertical_arm, armRL, armRR, H, W, D, arm_volume);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }

@@ -235,6 +235,30 @@ inline void FillTheHole(const int row, const int col, const int dispRange, float
     }
 }
 
+// ------------------------------------------------------------------ CBLSM.h:65-236
+// chooseArmLength{Left,Right,Up,Down} on host arm maps (call sites commented out in CBLSM.cpp:108-111)
+inline void choose_arm_length_(int dir, const int *own, const int *vert, const int *RL, const int *RR, int dispRange,
+                               int *Armvolume, int row, int col)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<int> a(n), v(n), l(n), r(n), out(n * dispRange);
+    a.upload(own); l.upload(RL); r.upload(RR);
+    if (vert) v.upload(vert);
+    check(smt_cblsm_choose_arm_length(dir, a.get(), vert ? v.get() : nullptr, l.get(), r.get(), row, col, dispRange,
+                                      out.get(), nullptr), "smt_cblsm_choose_arm_length");
+    out.download(Armvolume);
+}
+inline void chooseArmLengthLeft(int *ArmLL, int * /*ArmLR*/, int *ArmRL, int *ArmRR, int dispRange, int *Armvolume, int row, int col)
+{ choose_arm_length_(0, ArmLL, nullptr, ArmRL, ArmRR, dispRange, Armvolume, row, col); }
+inline void chooseArmLengthRight(int * /*ArmLL*/, int *ArmLR, int *ArmRL, int *ArmRR, int dispRange, int *Armvolume, int row, int col)
+{ choose_arm_length_(1, ArmLR, nullptr, ArmRL, ArmRR, dispRange, Armvolume, row, col); }
+inline void chooseArmLengthUp(int *ArmLUp, int * /*ArmLDown*/, int *ArmRUp, int * /*ArmRDown*/, int *ArmRL, int *ArmRR, int dispRange,
+                              int *Armvolume, int row, int col)
+{ choose_arm_length_(2, ArmLUp, ArmRUp, ArmRL, ArmRR, dispRange, Armvolume, row, col); }
+inline void chooseArmLengthDown(int * /*ArmLUp*/, int *ArmLDown, int * /*ArmRUp*/, int *ArmRDown, int *ArmRL, int *ArmRR, int dispRange,
+                                int *Armvolume, int row, int col)
+{ choose_arm_length_(3, ArmLDown, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col); }
+
 // ------------------------------------------------------------------ cross_aggregator.h:27-113
 struct CrossArm { uint8_t left, right, top, bottom; };
 

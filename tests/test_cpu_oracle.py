@@ -527,3 +527,59 @@ def test_fill_the_hole_python_restatement_equals_oracle(O, row, col, seed):
     # more holes than mismatch entries: the reference overruns fill_disps
     with pytest.raises(ValueError):
         O.fill_the_hole(d, D, occ, mis[:3])
+
+
+def test_choose_arm_length_closed_forms_equal_oracle(O):
+    """Independent closed forms of CBLSM.h:65-147 (left / right) and a plain-Python walk of the
+    up / down loops (:151-236) against the oracle's loop restatement."""
+    rng = np.random.default_rng(3)
+    row, col, D = 19, 27, 12
+    jj = np.arange(col)[None, :].repeat(row, 0)
+    ii = np.arange(row)[:, None].repeat(col, 1)
+    LL = np.minimum(rng.integers(0, 9, (row, col)), jj).astype(np.int32)
+    LR = np.minimum(rng.integers(0, 9, (row, col)), col - 1 - jj).astype(np.int32)
+    RL = np.minimum(rng.integers(0, 9, (row, col)), jj).astype(np.int32)
+    RR = np.minimum(rng.integers(0, 9, (row, col)), col - 1 - jj).astype(np.int32)
+    LU = np.minimum(rng.integers(0, 9, (row, col)), ii).astype(np.int32)
+    LD = np.minimum(rng.integers(0, 9, (row, col)), row - 1 - ii).astype(np.int32)
+    RU = np.minimum(rng.integers(0, 9, (row, col)), ii).astype(np.int32)
+    RD = np.minimum(rng.integers(0, 9, (row, col)), row - 1 - ii).astype(np.int32)
+    d = np.arange(D)[None, None, :]
+    # left: d must lie within [0, min(RL, RR)]; then the a with a + d <= RL, at most LL of them
+    left = np.where((d > RL[..., None]) | (d > RR[..., None]), 0,
+                    np.clip(np.minimum(LL[..., None], RL[..., None] - d), 0, None))
+    assert np.array_equal(O.choose_arm_length(0, LL, None, RL, RR, D), left)
+    # right: d <= RL; consecutive a = 1.. with a - d >= -RL (always, as d <= RL) and a - d < RR
+    right = np.where(d > RL[..., None], 0, np.clip(np.minimum(LR[..., None], RR[..., None] + d - 1), 0, None))
+    assert np.array_equal(O.choose_arm_length(1, LR, None, RL, RR, D), right)
+    up = np.zeros((row, col, D), np.int32)
+    dn = np.zeros((row, col, D), np.int32)
+    for i in range(row):
+        for j in range(col):
+            for dd in range(D):
+                s = 0
+                for u in range(1, LU[i, j] + 1):
+                    pr = i - u
+                    if pr >= i - RU[i, j]:
+                        if j - dd < 0:
+                            break
+                        if -RL[pr, j] < -dd < RR[pr, j]:
+                            s += 1
+                    else:
+                        s = 0
+                        break
+                up[i, j, dd] = s
+                s = 0
+                for u in range(1, LD[i, j] + 1):
+                    pr = i + u
+                    if pr <= i + RD[i, j]:
+                        if j - dd < 0:
+                            s = 0
+                            break
+                        if -RL[pr, j] <= -dd <= RR[pr, j]:
+                            s += 1
+                    else:
+                        break
+                dn[i, j, dd] = s
+    assert np.array_equal(O.choose_arm_length(2, LU, RU, RL, RR, D), up)
+    assert np.array_equal(O.choose_arm_length(3, LD, RD, RL, RR, D), dn)

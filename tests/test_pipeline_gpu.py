@@ -414,3 +414,24 @@ def test_config3_full_size_bands_vs_oracle(smt, O):
         rows = slice(700, 702)
         ref = O.scan_pass(agg[rows].cpu().numpy(), L[rows].astype(np.float32), 10, 150, which)
         assert np.array_equal(bits(out[rows].cpu().numpy()), bits(ref)), which
+
+
+@pytest.mark.parametrize("H,W,D,seed", [(40, 90, 16, 1), (33, 70, 64, 2), (25, 50, 100, 3)])
+def test_cblsm_choose_arm_length(smt, O, H, W, D, seed):
+    """CBLSM.h:65-236 (dead experiments): per-hypothesis arm volumes from the real arm
+    maps of a synthetic pair, all four directions, against the oracle's loop restatement."""
+    Li, Ri = O.synth_pair(H, W, 32, seed)
+    aL = O.arms_all(Li, 25, 6, 17, 34, chain=False, right_row_bug=False)
+    aR = O.arms_all(Ri, 25, 6, 17, 34, chain=False, right_row_bug=False)
+    dev = [[T(a) for a in aL], [T(a) for a in aR]]
+    (LL, LR, LU, LD), (RL, RR, RU, RD) = dev
+    got = [smt.chooseArmLengthLeft(LL, LR, RL, RR, D, None, H, W),
+           smt.chooseArmLengthRight(LL, LR, RL, RR, D, None, H, W),
+           smt.chooseArmLengthUp(LU, LD, RU, RD, RL, RR, D, None, H, W),
+           smt.chooseArmLengthDown(LU, LD, RU, RD, RL, RR, D, None, H, W)]
+    ref = [O.choose_arm_length(0, aL[0], None, aR[0], aR[1], D),
+           O.choose_arm_length(1, aL[1], None, aR[0], aR[1], D),
+           O.choose_arm_length(2, aL[2], aR[2], aR[0], aR[1], D),
+           O.choose_arm_length(3, aL[3], aR[3], aR[0], aR[1], D)]
+    for name, g, r in zip(("Left", "Right", "Up", "Down"), got, ref):
+        assert np.array_equal(g.cpu().numpy(), r), name
