@@ -51,7 +51,8 @@ struct Tables {
 //   cenX_R[xr] == cenA_R[xr] for xr >= 3      (no neighbour column is clamped to 0)
 //   cenX_L[xl] == cenA_L[xl] for xl <= W-4    (no neighbour wraps to column 0, centre unclamped)
 // so k_prep computes the two ordinary censuses + mask once per pixel from an LDS-staged 64x16 tile and
-// writes them to both places; k_prep_edges fills the 6 + 7 special columns per row.
+// writes them to both places; prep_edges (extra workgroups of the same launch) fills the 6 + 7 special
+// columns per row.
 constexpr int PTW = 64;                                     // tile: 64 columns x 16 rows per workgroup
 constexpr int PTH = 16;
 constexpr int PNT = 256;                                    // each thread does one column of 4 rows
@@ -63,12 +64,72 @@ __device__ __forceinline__ unsigned to_u8_checked(float a, bool &bad)
     return (unsigned)ia & 0xffu;
 }
 
+// the border columns of the extended tables: xr in [-3, 2] and xl in [W-3, W+3], by the general rule.
+// Runs in extra workgroups of the k_prep launch (16 rows each, 13 of 16 lanes per row), reading the
+// float images directly (their domain is checked by the tile workgroups).
+__device__ __forceinline__ void prep_edges(const float *__restrict__ Lf, const float *__restrict__ Rf, int H, int W,
+                                           const Tables &T, int block)
+{
+    const int i = block * (PNT / 16) + (threadIdx.x >> 4);
+    const int e = threadIdx.x & 15;
+    if (i >= H || e >= 13) return;
+    const int WX = T.WX;
+    if (e < 6) {
+        const int xr = e - 3;
+        if (xr > W - 1) return;                          // narrower than 3 columns
+        const int cc = xr < 0 ? 0 : xr;
+        const unsigned rc = (unsigned)(int)Rf[(size_t)i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                int jj = xr + c;
+                jj = jj < 0 ? 0 : jj;                    // left replicate (:177-178)
+                const bool v = rv && jj < W;
+                const unsigned val = (unsigned)(int)Rf[(size_t)ic * W + (jj < W ? jj : W - 1)];
+                w = (w << 1) | (uint64_t)(v && rc > val);
+            }
+        }
+        T.cenX[0][(size_t)i * WX + e] = w;
+    } else {
+        const int xl = W - 3 + (e - 6);
+        if (xl < 0) return;
+        const int cc = xl > W - 1 ? W - 1 : xl;          // centre clamps to W-1 (:224-225)
+        const unsigned lc = (unsigned)(int)Lf[(size_t)i * W + cc];
+        uint64_t w = 0;
+#pragma unroll
+        for (int r = -4; r <= 4; r++) {
+            const int ii = i + r;
+            const bool rv = (ii >= 0 && ii < H);
+            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+#pragma unroll
+            for (int c = -3; c <= 3; c++) {
+                int jj = xl + c;
+                jj = jj >= W ? 0 : jj;                   // neighbour wraps to column 0 (:242-243)
+                const bool v = rv && jj >= 0;
+                const unsigned val = (unsigned)(int)Lf[(size_t)ic * W + (jj < 0 ? 0 : jj)];
+                w = (w << 1) | (uint64_t)(v && lc > val);
+            }
+        }
+        T.cenX[1][(size_t)i * WX + xl] = w;
+    }
+}
+
 __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
                                               int H, int W, Tables T)
 {
     constexpr int SR = PTH + 8, SC = PTW + 6;               // staged rows / columns (4-row, 3-column halo)
     __shared__ uint8_t sL[SR][SC + 2];
     __shared__ uint8_t sR[SR][SC + 2];
+    const int tiles_y = (H + PTH - 1) / PTH;
+    if ((int)blockIdx.y >= tiles_y) {                       // workgroup-uniform, before any barrier
+        prep_edges(Lf, Rf, H, W, T, ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x);
+        return;
+    }
     const int i0 = blockIdx.y * PTH;
     const int x0 = blockIdx.x * PTW;
     const int tid = threadIdx.x;
@@ -123,59 +184,6 @@ __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, cons
         T.mask[p] = m;
         if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cr;      // cenX_R index = xr + 3
         if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cl;      // cenX_L index = xl
-    }
-}
-
-// the border columns of the extended tables: xr in [-3, 2] and xl in [W-3, W+3]
-__global__ void __launch_bounds__(64) k_prep_edges(int H, int W, Tables T)
-{
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 4);
-    const int e = threadIdx.x & 15;
-    if (i >= H || e >= 13) return;
-    const uint8_t *Lb = T.u8[0], *Rb = T.u8[1];
-    const int WX = T.WX;
-    if (e < 6) {
-        const int xr = e - 3;
-        if (xr > W - 1) return;                          // narrower than 3 columns
-        const int cc = xr < 0 ? 0 : xr;
-        const unsigned rc = Rb[(size_t)i * W + cc];
-        uint64_t w = 0;
-#pragma unroll
-        for (int r = -4; r <= 4; r++) {
-            const int ii = i + r;
-            const bool rv = (ii >= 0 && ii < H);
-            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
-#pragma unroll
-            for (int c = -3; c <= 3; c++) {
-                int jj = xr + c;
-                jj = jj < 0 ? 0 : jj;                    // left replicate (:177-178)
-                const bool v = rv && jj < W;
-                const unsigned val = Rb[(size_t)ic * W + (jj < W ? jj : W - 1)];
-                w = (w << 1) | (uint64_t)(v && rc > val);
-            }
-        }
-        T.cenX[0][(size_t)i * WX + e] = w;
-    } else {
-        const int xl = W - 3 + (e - 6);
-        if (xl < 0) return;
-        const int cc = xl > W - 1 ? W - 1 : xl;          // centre clamps to W-1 (:224-225)
-        const unsigned lc = Lb[(size_t)i * W + cc];
-        uint64_t w = 0;
-#pragma unroll
-        for (int r = -4; r <= 4; r++) {
-            const int ii = i + r;
-            const bool rv = (ii >= 0 && ii < H);
-            const int ic = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
-#pragma unroll
-            for (int c = -3; c <= 3; c++) {
-                int jj = xl + c;
-                jj = jj >= W ? 0 : jj;                   // neighbour wraps to column 0 (:242-243)
-                const bool v = rv && jj >= 0;
-                const unsigned val = Lb[(size_t)ic * W + (jj < 0 ? 0 : jj)];
-                w = (w << 1) | (uint64_t)(v && lc > val);
-            }
-        }
-        T.cenX[1][(size_t)i * WX + xl] = w;
     }
 }
 
@@ -726,8 +734,12 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     hipStream_t ps = overlap ? h->prep_stream : h->stream;
     if (overlap && h->n_pairs >= 2) SMT_HIP(hipStreamWaitEvent(ps, h->cost_done[set], 0));
     if (timed) (void)hipEventRecord(ev[0], ps);
-    hipLaunchKernelGGL(k_prep, dim3((W + PTW - 1) / PTW, (H + PTH - 1) / PTH), dim3(PNT), 0, ps, L, R, H, W, h->T);
-    hipLaunchKernelGGL(k_prep_edges, dim3((H + 3) / 4), dim3(64), 0, ps, H, W, h->T);
+    {
+        // tile workgroups + the workgroups of the 13 border columns (16 rows each) in one launch
+        const int tx = (W + PTW - 1) / PTW, ty = (H + PTH - 1) / PTH;
+        const int eb = (H + PNT / 16 - 1) / (PNT / 16);
+        hipLaunchKernelGGL(k_prep, dim3(tx, ty + (eb + tx - 1) / tx), dim3(PNT), 0, ps, L, R, H, W, h->T);
+    }
     if (timed) (void)hipEventRecord(ev[1], ps);
     if (overlap) {
         SMT_HIP(hipEventRecord(h->prep_done[set], ps));
