@@ -50,12 +50,12 @@ struct Tables {
 // Away from the left/right borders the extended tables equal the ordinary censuses:
 //   cenX_R[xr] == cenA_R[xr] for xr >= 3      (no neighbour column is clamped to 0)
 //   cenX_L[xl] == cenA_L[xl] for xl <= W-4    (no neighbour wraps to column 0, centre unclamped)
-// so k_prep computes the two ordinary censuses + mask once per pixel from an LDS-staged 64x16 tile and
+// so k_prep computes the two ordinary censuses + mask once per pixel from an LDS-staged 64x32 tile and
 // writes them to both places; prep_edges (extra workgroups of the same launch) fills the 6 + 7 special
 // columns per row.
-constexpr int PTW = 64;                                     // tile: 64 columns x 16 rows per workgroup
-constexpr int PTH = 16;
-constexpr int PNT = 256;                                    // each thread does one column of 4 rows
+constexpr int PTW = 64;                                     // tile: 64 columns x 32 rows per workgroup
+constexpr int PTH = 32;
+constexpr int PNT = 256;                                    // each thread does one column of 8 rows
 
 __device__ __forceinline__ unsigned to_u8_checked(float a, bool &bad)
 {
@@ -123,8 +123,9 @@ __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, cons
                                               int H, int W, Tables T)
 {
     constexpr int SR = PTH + 8, SC = PTW + 6;               // staged rows / columns (4-row, 3-column halo)
-    __shared__ uint8_t sL[SR][SC + 2];
-    __shared__ uint8_t sR[SR][SC + 2];
+    constexpr int SW = (SC + 2 + 3) / 4 + 1;                // row stride in dwords (one spare for the 3rd dword)
+    __shared__ uint32_t sLw[SR][SW];
+    __shared__ uint32_t sRw[SR][SW];
     const int tiles_y = (H + PTH - 1) / PTH;
     if ((int)blockIdx.y >= tiles_y) {                       // workgroup-uniform, before any barrier
         prep_edges(Lf, Rf, H, W, T, ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x);
@@ -141,41 +142,65 @@ __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, cons
         int ii = i0 + r - 4, jj = x0 + c - 3;
         ii = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
         jj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
-        sL[r][c] = (uint8_t)to_u8_checked(Lf[(size_t)ii * W + jj], bad);
-        sR[r][c] = (uint8_t)to_u8_checked(Rf[(size_t)ii * W + jj], bad);
+        ((uint8_t *)sLw[r])[c] = (uint8_t)to_u8_checked(Lf[(size_t)ii * W + jj], bad);
+        ((uint8_t *)sRw[r])[c] = (uint8_t)to_u8_checked(Rf[(size_t)ii * W + jj], bad);
     }
     if (__syncthreads_or(bad) && tid == 0) atomicOr(T.flag, 1);
     const int col = tid & (PTW - 1);
     const int x = x0 + col;
     if (x >= W) return;
-#pragma unroll 1
-    for (int rr = 0; rr < PTH / (PNT / PTW); rr++) {
-        const int row = (tid / PTW) * (PTH / (PNT / PTW)) + rr;
-        const int i = i0 + row;
+    constexpr int RPT = PTH / (PNT / PTW);                  // output rows per thread (consecutive)
+    const int row0 = (tid / PTW) * RPT;
+    // The thread's 7-byte window [col, col+6] of each of the RPT+8 staged rows it needs, as two dwords
+    // per image: three aligned LDS dwords shifted by col%4 bytes.  Bytes past col+6 are never used.
+    const int cw = col >> 2;
+    const unsigned sh = (unsigned)(col & 3);
+    uint32_t wl0[RPT + 8], wl1[RPT + 8], wr0[RPT + 8], wr1[RPT + 8];
+#pragma unroll
+    for (int r = 0; r < RPT + 8; r++) {
+        const uint32_t a0 = sLw[row0 + r][cw], a1 = sLw[row0 + r][cw + 1], a2 = sLw[row0 + r][cw + 2];
+        const uint32_t b0 = sRw[row0 + r][cw], b1 = sRw[row0 + r][cw + 1], b2 = sRw[row0 + r][cw + 2];
+        wl0[r] = __builtin_amdgcn_alignbyte(a1, a0, sh); wl1[r] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+        wr0[r] = __builtin_amdgcn_alignbyte(b1, b0, sh); wr1[r] = __builtin_amdgcn_alignbyte(b2, b1, sh);
+    }
+    // column validity of the 7 taps, MSB = leftmost tap
+    unsigned colbits = 0;
+#pragma unroll
+    for (int c = 0; c < 7; c++) colbits |= (unsigned)(x + c - 3 >= 0 && x + c - 3 < W) << (6 - c);
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        const int i = i0 + row0 + rr;
         if (i >= H) break;
-        T.u8[0][(size_t)i * W + x] = sL[row + 4][col + 3];
-        T.u8[1][(size_t)i * W + x] = sR[row + 4][col + 3];
-        // Branch-free: every staged byte is readable, the raw comparison bits are masked afterwards with
-        // the tap-validity word.  Bits are assembled in two 32-bit halves with compile-time positions
-        // (tap t -> bit 62-t).
-        const unsigned lc = sL[row + 4][col + 3], rc = sR[row + 4][col + 3];
-        unsigned clh = 0, cll = 0, crh = 0, crl = 0, mh = 0, ml = 0;
+        // centre = byte 3 of the window of staged row rr+4
+        const int lc = (int)(wl0[rr + 4] >> 24), rc = (int)(wr0[rr + 4] >> 24);
+        T.u8[0][(size_t)i * W + x] = (uint8_t)lc;
+        T.u8[1][(size_t)i * W + x] = (uint8_t)rc;
+        // census word, MSB first over taps t = r*7 + c: bit = centre > neighbour = sign of
+        // (neighbour - centre), shifted in with one v_alignbit per tap.  Taps 0..30 fill the high word
+        // (bits 62..32), taps 31..62 the low word; every staged byte is readable, the raw bits are
+        // masked afterwards with the tap-validity word.
+        uint32_t clh = 0, cll = 0, crh = 0, crl = 0;
+        uint64_t m = 0;
 #pragma unroll
         for (int r = 0; r < 9; r++) {
             const int ii = i + r - 4;
-            const unsigned rv = (ii >= 0 && ii < H) ? 1u : 0u;
+            if (ii >= 0 && ii < H) m |= (uint64_t)colbits << (56 - 7 * r);
 #pragma unroll
             for (int c = 0; c < 7; c++) {
-                const int pos = 62 - (r * 7 + c);
-                const int jj = x + c - 3;
-                const unsigned v = rv & ((jj >= 0 && jj < W) ? 1u : 0u);
-                const unsigned bl = (lc > (unsigned)sL[row + r][col + c]) ? 1u : 0u;
-                const unsigned br = (rc > (unsigned)sR[row + r][col + c]) ? 1u : 0u;
-                if (pos >= 32) { clh |= bl << (pos - 32); crh |= br << (pos - 32); mh |= v << (pos - 32); }
-                else           { cll |= bl << pos;        crl |= br << pos;        ml |= v << pos; }
+                const int t = r * 7 + c;
+                const uint32_t wl = c < 4 ? wl0[rr + r] : wl1[rr + r];
+                const uint32_t wr = c < 4 ? wr0[rr + r] : wr1[rr + r];
+                const int dl = (int)((wl >> (8 * (c & 3))) & 0xffu) - lc;
+                const int dr = (int)((wr >> (8 * (c & 3))) & 0xffu) - rc;
+                if (t < 31) {
+                    clh = __builtin_amdgcn_alignbit(clh, (uint32_t)dl, 31);
+                    crh = __builtin_amdgcn_alignbit(crh, (uint32_t)dr, 31);
+                } else {
+                    cll = __builtin_amdgcn_alignbit(cll, (uint32_t)dl, 31);
+                    crl = __builtin_amdgcn_alignbit(crl, (uint32_t)dr, 31);
+                }
             }
         }
-        const uint64_t m = ((uint64_t)mh << 32) | ml;
         const uint64_t cl = (((uint64_t)clh << 32) | cll) & m;
         const uint64_t cr = (((uint64_t)crh << 32) | crl) & m;
         const size_t p = (size_t)i * W + x;
