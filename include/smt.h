@@ -71,7 +71,7 @@ int smt_stream_destroy(void *stream);
 int smt_stream_sync(void *stream); /* synchronising */
 
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------
- * When enabled, every pair processed on the handle records four HIP events -- around the table
+ * When enabled, every N-th pair processed on the handle records HIP events -- around the table
  * kernels on the handle's internal stream and around the cost kernel(s) on the caller's stream, i.e.
  * each on the stream the kernels are launched on -- into a ring of `SMT_TIMING_SLOTS` slots; nothing
  * synchronises until
@@ -79,7 +79,7 @@ int smt_stream_sync(void *stream); /* synchronising */
  * durations in milliseconds, oldest first. */
 #define SMT_TIMING_SLOTS 1024
 typedef struct smt_adcensus smt_adcensus;
-int smt_adcensus_timing(smt_adcensus *h, int enable); /* also clears the ring */
+int smt_adcensus_timing(smt_adcensus *h, int enable); /* 0 off, N > 0: record every N-th pair; also clears the ring */
 int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *cost_ms, int capacity,
                               int *count);
 

@@ -137,6 +137,8 @@ class AD_Census:
         check(lib().smt_adcensus_force_generic(self._h, int(on)), "smt_adcensus_force_generic")
 
     def timing(self, enable=True):
+        """False / 0: off.  True / 1: record HIP events around the kernels of every pair; N > 1: of every
+        N-th pair (an event record costs about 3 us on the stream)."""
         check(lib().smt_adcensus_timing(self._h, int(enable)), "smt_adcensus_timing")
 
     def kernel_times(self):

@@ -563,6 +563,9 @@ struct smt_adcensus {
     bool timing;
     bool force_generic;  // test hook: route D%64==0 through the generic kernel too
     long n_timed;        // pairs recorded since timing was (re-)enabled
+    long n_seen;         // pairs processed since timing was (re-)enabled
+    int timing_stride;   // every timing_stride-th pair is recorded
+    bool *ev_merged;     // slot recorded 3 events (tables end == cost start, one stream)
 };
 
 SMT_API const char *smt_strerror(int s)
@@ -628,7 +631,7 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     smt_adcensus *h = new (std::nothrow) smt_adcensus();
     if (!h) return SMT_ERR_ALLOC;
     h->H = H; h->W = W; h->D = D; h->sigmaC = sigmaC; h->sigmaS = sigmaS;
-    h->stream = nullptr; h->timing = false; h->force_generic = false; h->ev = nullptr; h->n_timed = 0;
+    h->stream = nullptr; h->timing = false; h->force_generic = false; h->ev = nullptr; h->n_timed = 0; h->n_seen = 0; h->timing_stride = 1; h->ev_merged = nullptr;
     h->n_pairs = 0;
     const size_t N = (size_t)H * W, V = N * D;
     const int WX = W + 4;
@@ -696,6 +699,7 @@ SMT_API int smt_adcensus_destroy(smt_adcensus *h)
     (void)hipFree(h->TS[0].lut); (void)hipFree(h->TS[0].flag);
     if (h->ev) {
         for (int k = 0; k < SMT_TIMING_SLOTS * 4; k++) (void)hipEventDestroy(h->ev[k]);
+        delete[] h->ev_merged;
         delete[] h->ev;
     }
     delete h;
@@ -752,8 +756,9 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     const int H = h->H, W = h->W, D = h->D;
     const int set = (int)(h->n_pairs & 1);
     h->T = h->TS[set];
-    const bool timed = h->timing;
-    hipEvent_t *ev = timed ? h->ev + 4 * (h->n_timed % SMT_TIMING_SLOTS) : nullptr;
+    const bool timed = h->timing && (h->n_seen++ % h->timing_stride) == 0;
+    const long slot = h->n_timed % SMT_TIMING_SLOTS;
+    hipEvent_t *ev = timed ? h->ev + 4 * slot : nullptr;
     // overlap == false: everything in order on the caller's stream (single pairs, first pair of a
     // batch, and images large enough that the cost kernel fills the chip by itself)
     hipStream_t ps = overlap ? h->prep_stream : h->stream;
@@ -770,7 +775,8 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
         SMT_HIP(hipEventRecord(h->prep_done[set], ps));
         SMT_HIP(hipStreamWaitEvent(h->stream, h->prep_done[set], 0));
     }
-    if (timed) (void)hipEventRecord(ev[2], h->stream);
+    // one stream: the event after the table kernels is also the cost kernel's start
+    if (timed) { h->ev_merged[slot] = !overlap; if (overlap) (void)hipEventRecord(ev[2], h->stream); }
     const int view0 = (views & SMT_VIEW_LEFT) ? 0 : 1;
     const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
     const int C = (D + 63) / 64;
@@ -858,11 +864,15 @@ SMT_API int smt_adcensus_timing(smt_adcensus *h, int enable)
     if (!h) return SMT_ERR_ARG;
     if (enable && !h->ev) {
         h->ev = new (std::nothrow) hipEvent_t[SMT_TIMING_SLOTS * 4];
-        if (!h->ev) return SMT_ERR_ALLOC;
+        h->ev_merged = new (std::nothrow) bool[SMT_TIMING_SLOTS]();
+        if (!h->ev || !h->ev_merged) return SMT_ERR_ALLOC;
         for (int k = 0; k < SMT_TIMING_SLOTS * 4; k++) SMT_HIP(hipEventCreate(&h->ev[k]));
     }
+    if (enable < 0) return SMT_ERR_ARG;
     h->timing = enable != 0;
+    h->timing_stride = enable > 0 ? enable : 1;
     h->n_timed = 0;
+    h->n_seen = 0;
     return SMT_OK;
 }
 
@@ -879,7 +889,8 @@ SMT_API int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *co
         SMT_HIP(hipEventSynchronize(ev[3]));
         float a = 0, b = 0;
         SMT_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));      // table kernels, internal stream
-        SMT_HIP(hipEventElapsedTime(&b, ev[2], ev[3]));      // cost kernel(s), caller's stream
+        const long slot = (first + k) % SMT_TIMING_SLOTS;
+        SMT_HIP(hipEventElapsedTime(&b, ev[h->ev_merged[slot] ? 1 : 2], ev[3]));   // cost kernel(s), caller's stream
         if (prep_ms) prep_ms[k] = a;
         if (cost_ms) cost_ms[k] = b;
     }

@@ -237,3 +237,34 @@ def test_volumes_start_zeroed_like_the_reference(smt):
     adc = smt.AD_Census().Initialize(z, z, 64, 6, 40, 10.0, 30.0)
     assert float(adc.GetPtrLeft().abs().max()) == 0.0 and float(adc.GetPtrRight().abs().max()) == 0.0
     adc.close()
+
+
+def test_kernel_timing_ring(smt):
+    """smt_adcensus_timing(N): HIP events around the kernels of every N-th pair, on the kernels' own
+    stream; durations come back oldest first and are plausible."""
+    from stereo_match_traditional_amd import synth
+    DEV = torch.device("cuda:0")
+    H, W, D = 120, 200, 64
+    L, R = synth.synth_pair(H, W, D, 9)
+    Lf = torch.from_numpy(L.astype(np.float32)).to(DEV)
+    Rf = torch.from_numpy(R.astype(np.float32)).to(DEV)
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10, 30)
+    dl = torch.empty((H, W), device=DEV); dr = torch.empty((H, W), device=DEV)
+    for stride, calls, expect in ((1, 6, 6), (4, 10, 3), (3, 3, 1)):
+        adc.timing(stride)
+        for _ in range(calls):
+            adc.ComputeBoth(dl, dr)
+        prep, cost = adc.kernel_times()
+        assert len(prep) == len(cost) == expect
+        assert all(0 < t < 50 for t in prep + cost)
+    adc.timing(False)
+    adc.ComputeBoth(dl, dr)
+    assert adc.kernel_times() == ([], [])
+    # a batch with the table kernels on the internal stream records the four-event form
+    Lb, Rb = Lf[None].repeat(3, 1, 1), Rf[None].repeat(3, 1, 1)
+    dlb = torch.empty((3, H, W), device=DEV); drb = torch.empty((3, H, W), device=DEV)
+    adc.timing(1)
+    adc.ComputeBatch(Lb, Rb, dlb, drb)
+    prep, cost = adc.kernel_times()
+    assert len(cost) == 3 and all(0 < t < 50 for t in prep + cost)
+    adc.close()
