@@ -1,26 +1,51 @@
 // Micro-benchmark: what HBM write rate does the cost kernel's store pattern reach with NO compute?
-// Same grid as k_cost_fast2 at 1920x1080, D=192 (30 x 1080 x 2 workgroups of 4 waves; each wave writes 16
-// consecutive pixels x 768 B with one dwordx3 per lane), vs a plain float4 grid-stride fill of the same bytes.
+// Same grid as k_cost_fast2 (ceil(W/64) x H x 2 workgroups of 4 waves; each wave writes 16 consecutive
+// pixels x D*4 B with one dword{x2,x3,x4} per lane = "rows"), against two alternatives over the same
+// bytes: the wave's 16*D*4 contiguous bytes written as flat 1 KB dwordx4 stores ("flat"), and a plain
+// float4 grid-stride fill.
 // Build & run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/store_ceiling.hip -o /tmp/sc && /tmp/sc
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-struct f3 { float v[3]; };
+template <int C> struct fv { float v[C]; };
+template <> struct __attribute__((aligned(8))) fv<2> { float v[2]; };
+template <> struct __attribute__((aligned(16))) fv<4> { float v[4]; };
 
-__global__ void __launch_bounds__(256) k_pattern(float *vol0, float *vol1, int H, int W)
+template <int C>
+__global__ void __launch_bounds__(256) k_rows(float *vol0, float *vol1, int H, int W)
 {
-    constexpr int D = 192, FTJ = 64, FPW = 16;
+    constexpr int D = 64 * C, FTJ = 64, FPW = 16;
     float *vol = blockIdx.z ? vol1 : vol0;
     const int i = blockIdx.y, j0 = blockIdx.x * FTJ;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int p0 = wid * FPW;
-    float *out = vol + ((size_t)i * W + j0 + p0) * D + lane * 3;
+    float *out = vol + ((size_t)i * W + j0 + p0) * D + lane * C;
     const int npx = min(FPW, W - (j0 + p0));
-    f3 x = {{(float)lane, 1.0f, 2.0f}};
+    fv<C> x;
+    for (int k = 0; k < C; k++) x.v[k] = (float)(lane + k);
     for (int q = 0; q < npx; q++) {
-        *reinterpret_cast<f3 *>(out) = x;
+        *reinterpret_cast<fv<C> *>(out) = x;
         out += D;
         x.v[0] += 1.0f;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_flat(float *vol0, float *vol1, int H, int W)
+{
+    constexpr int D = 64 * C, FTJ = 64, FPW = 16;
+    float *vol = blockIdx.z ? vol1 : vol0;
+    const int i = blockIdx.y, j0 = blockIdx.x * FTJ;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int p0 = wid * FPW;
+    const int npx = min(FPW, W - (j0 + p0));
+    float4 *out = reinterpret_cast<float4 *>(vol + ((size_t)i * W + j0 + p0) * D) + lane;
+    float4 x = make_float4((float)lane, 1.f, 2.f, 3.f);
+    const int n4 = npx * D / 4;                        // float4 per wave region
+    for (int q = lane; q < n4; q += 64) {
+        *out = x;
+        out += 64;
+        x.x += 1.0f;
     }
 }
 
@@ -30,26 +55,40 @@ __global__ void __launch_bounds__(256) k_fill4(float4 *p, size_t n)
         p[k] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
-int main()
+template <int C>
+static void run(int H, int W)
 {
-    const int H = 1080, W = 1920, D = 192;
+    const int D = 64 * C;
     const size_t V = (size_t)H * W * D;
     float *a, *b;
     hipMalloc(&a, V * 4); hipMalloc(&b, V * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms;
+    const dim3 grid((W + 63) / 64, H, 2);
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
-        for (int k = 0; k < 20; k++) hipLaunchKernelGGL(k_pattern, dim3(30, H, 2), dim3(256), 0, 0, a, b, H, W);
+        for (int k = 0; k < 20; k++) hipLaunchKernelGGL(k_rows<C>, grid, dim3(256), 0, 0, a, b, H, W);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        printf("pattern   : %.4f ms per pair-equivalent, %.1f GB/s\n", ms / 20, 2.0 * V * 4 / (ms / 20 * 1e-3) / 1e9);
+        printf("%dx%d D=%d rows       : %.4f ms per pair-equivalent, %.1f GB/s\n", W, H, D, ms / 20, 2.0 * V * 4 / (ms / 20 * 1e-3) / 1e9);
+        hipEventRecord(e0);
+        for (int k = 0; k < 20; k++) hipLaunchKernelGGL(k_flat<C>, grid, dim3(256), 0, 0, a, b, H, W);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("%dx%d D=%d flat 1 KB  : %.4f ms per pair-equivalent, %.1f GB/s\n", W, H, D, ms / 20, 2.0 * V * 4 / (ms / 20 * 1e-3) / 1e9);
         hipEventRecord(e0);
         for (int k = 0; k < 20; k++) {
             hipLaunchKernelGGL(k_fill4, dim3(2048), dim3(256), 0, 0, (float4 *)a, V / 4);
             hipLaunchKernelGGL(k_fill4, dim3(2048), dim3(256), 0, 0, (float4 *)b, V / 4);
         }
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        printf("float4 fill: %.4f ms per pair-equivalent, %.1f GB/s\n", ms / 20, 2.0 * V * 4 / (ms / 20 * 1e-3) / 1e9);
+        printf("%dx%d D=%d float4 fill: %.4f ms per pair-equivalent, %.1f GB/s\n", W, H, D, ms / 20, 2.0 * V * 4 / (ms / 20 * 1e-3) / 1e9);
     }
+    hipFree(a); hipFree(b);
+}
+
+int main()
+{
+    run<3>(1080, 1920);
+    run<2>(720, 1280);
+    run<4>(375, 1242);
     return 0;
 }
