@@ -350,7 +350,7 @@ struct __attribute__((aligned(16))) Anchor { uint64_t cen, mask; };
 // the window slots those elements would touch.
 template <int C, int VIEW, bool FULL>
 __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tables &T, float *__restrict__ vol,
-                                               float *__restrict__ disp)
+                                               float *__restrict__ disp, int i, int bx)
 {
     constexpr int DM = 64 * C;                               // largest D this instantiation serves
     constexpr int XPAD = 4;
@@ -365,8 +365,7 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
     uint64_t *s_cenx = s_cenx_raw + XPAD;                    // entry e in [-XPAD, NX + XPAD)
     uint16_t *s_valx = s_valx_raw + XPAD;
 
-    const int i = blockIdx.y;
-    const int j0 = blockIdx.x * FTJ;
+    const int j0 = bx * FTJ;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -499,21 +498,45 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
     if (disp && lane < npx) disp[(size_t)i * W + j0 + p0 + lane] = (float)res;
 }
 
-template <int C, int VIEW, bool FULL>
-__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, int D, Tables T, float *__restrict__ vol,
-                                                  float *__restrict__ disp)
+// Workgroup -> 64-pixel chunk.  The chunks of a launch form one linear space (view, row, chunk-in-row)
+// and workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), so XCD x takes the x-th contiguous eighth of
+// that space: every XCD then streams its own region of the volumes instead of every eighth 48 KB piece
+// of the same region.  A store-only kernel with this mapping writes 10 % faster (6.9 vs 6.25 TB/s,
+// same box) than with chunks in dispatch order.  The grid is 1-D, padded to a multiple of 8.
+__device__ __forceinline__ bool chunk_of_block(int nbx, int H, int nviews, int &view, int &i, int &bx)
 {
-    cost_fast_body<C, VIEW, FULL>(H, W, D, T, vol, disp);
+    const long nb = (long)nbx * H * nviews;
+    const long per = (nb + 7) >> 3;
+    const long b = blockIdx.x;
+    const long c = (b & 7) * per + (b >> 3);
+    if (c >= nb) return false;
+    const long rows = (long)nbx * H;
+    view = (int)(c / rows);
+    const long r = c - (long)view * rows;
+    i = (int)(r / nbx);
+    bx = (int)(r - (long)i * nbx);
+    return true;
 }
 
-// both views in one launch: blockIdx.z selects the view (no gap / tail between two launches)
+template <int C, int VIEW, bool FULL>
+__global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, int D, Tables T, float *__restrict__ vol,
+                                                  float *__restrict__ disp, int nbx)
+{
+    int view, i, bx;
+    if (!chunk_of_block(nbx, H, 1, view, i, bx)) return;
+    cost_fast_body<C, VIEW, FULL>(H, W, D, T, vol, disp, i, bx);
+}
+
+// both views in one launch (no gap / tail between two launches)
 template <int C, bool FULL>
 __global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T, float *__restrict__ vol0,
                                                    float *__restrict__ vol1, float *__restrict__ disp0,
-                                                   float *__restrict__ disp1)
+                                                   float *__restrict__ disp1, int nbx)
 {
-    if (blockIdx.z == 0) cost_fast_body<C, 0, FULL>(H, W, D, T, vol0, disp0);
-    else cost_fast_body<C, 1, FULL>(H, W, D, T, vol1, disp1);
+    int view, i, bx;
+    if (!chunk_of_block(nbx, H, 2, view, i, bx)) return;
+    if (view == 0) cost_fast_body<C, 0, FULL>(H, W, D, T, vol0, disp0, i, bx);
+    else cost_fast_body<C, 1, FULL>(H, W, D, T, vol1, disp1, i, bx);
 }
 
 // WTA over an existing volume: one wave per pixel, lane owns C consecutive d (one vector load when
@@ -728,19 +751,19 @@ static void launch_cost(smt_adcensus *h, int view0, int nviews, float *d0, float
 template <int C, bool FULL>
 static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
 {
-    dim3 grid((h->W + FTJ - 1) / FTJ, h->H);
+    const int nbx = (h->W + FTJ - 1) / FTJ;
+    auto blocks = [&](int nviews) { return dim3((unsigned)(((long)nbx * h->H * nviews + 7) / 8 * 8)); };
     if (views == SMT_VIEW_BOTH) {
-        dim3 g2(grid.x, grid.y, 2);
-        hipLaunchKernelGGL((k_cost_fast2<C, FULL>), g2, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
-                           h->vol[1], dL, dR);
+        hipLaunchKernelGGL((k_cost_fast2<C, FULL>), blocks(2), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
+                           h->vol[1], dL, dR, nbx);
         return;
     }
     if (views & SMT_VIEW_LEFT)
-        hipLaunchKernelGGL((k_cost_fast<C, 0, FULL>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
-                           h->vol[0], dL);
+        hipLaunchKernelGGL((k_cost_fast<C, 0, FULL>), blocks(1), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
+                           h->vol[0], dL, nbx);
     if (views & SMT_VIEW_RIGHT)
-        hipLaunchKernelGGL((k_cost_fast<C, 1, FULL>), grid, dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
-                           h->vol[1], dR);
+        hipLaunchKernelGGL((k_cost_fast<C, 1, FULL>), blocks(1), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
+                           h->vol[1], dR, nbx);
 }
 
 // One pair into table set (n & 1).  With overlap the table kernels run on the handle's internal

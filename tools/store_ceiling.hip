@@ -85,10 +85,16 @@ static void run(int H, int W)
     hipFree(a); hipFree(b);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     run<3>(1080, 1920);
     run<2>(720, 1280);
     run<4>(375, 1242);
+    if (argc > 1) {                                    // size vs row-stride: which one lowers the 1080p D=192 rate?
+        run<2>(1080, 1920);
+        run<4>(1080, 1920);
+        run<3>(720, 1280);
+        run<3>(375, 1242);
+    }
     return 0;
 }
