@@ -435,3 +435,27 @@ def test_cblsm_choose_arm_length(smt, O, H, W, D, seed):
            O.choose_arm_length(3, aL[3], aR[3], aR[0], aR[1], D)]
     for name, g, r in zip(("Left", "Right", "Up", "Down"), got, ref):
         assert np.array_equal(g.cpu().numpy(), r), name
+
+
+def test_aggregation_variants_agree_above_2gib(smt):
+    """A 2.7 GB volume: tap byte offsets need all 32 bits (the buffer descriptor's num_records and the
+    SGPR tap offsets are unsigned).  GPU-only property: the shared-tap kernels equal the plain walk."""
+    H, W, D = 1300, 2000, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    vol = torch.rand((H, W, D), device=DEV, generator=g) * 2
+    img = (torch.arange(H, device=DEV)[:, None] // 11 * 9 + torch.arange(W, device=DEV)[None, :] // 17 * 13) % 200
+    img = (img + torch.randint(0, 5, (H, W), device=DEV, generator=g)).to(torch.uint8)
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.ComputeArmLengths(img)
+    ref = torch.empty((H, W, D), device=DEV)
+    ca.set_variant(1)
+    ca.AggregationVertical(vol, ref)
+    ca.status()
+    out = torch.empty((H, W, D), device=DEV)
+    for variant in (4, 3, 0):
+        out.zero_()
+        ca.set_variant(variant)
+        ca.AggregationVertical(vol, out)
+        ca.status()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), variant
+    ca.close()
