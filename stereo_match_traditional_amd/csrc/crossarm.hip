@@ -709,7 +709,9 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
         for (int k = 0; k < C; k++) {
             const float v = a[k] / fc;
             if (FULL || dl + k < D) {
-                dst[k] = v;
+                // streaming store: the output is not read by this kernel and would otherwise evict input
+                // taps from L2
+                __builtin_nontemporal_store(v, dst + k);
                 if (k == 0 || best > v) { best = v; bk = k; }
             }
         }
