@@ -64,6 +64,10 @@ __global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img
     const int dir = blockIdx.y;
     const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
     const int idx = blockIdx.x * NT + threadIdx.x;
+    // only the smallest qualifying index matters: workgroups behind a candidate already found have
+    // nothing to add (workgroups are dispatched in index order, so on images that flip early almost
+    // all of them leave here)
+    if ((int)(blockIdx.x * NT) > *(volatile int *)&flip[dir]) return;
     bool ok = idx < c.H * colR;
     const int i = ok ? idx / colR : 0, j = ok ? idx - i * colR : 0;
     for (int k = 1; k <= c.sec && ok; k++) {
