@@ -64,21 +64,50 @@ __global__ void __launch_bounds__(NT) k_sad(const uint8_t *__restrict__ Lp, cons
     }
     const int dmax = (view == 0) ? jo : (W - 1 - jo);                     // last in-range disparity
     float sad[KMAX];
+    // top-left corners of the two windows in padded coordinates; hypothesis d is evaluated at min(d, dmax)
+    const uint8_t *a = (view == 0 ? Lp : Rp) + (size_t)io * Wp + jo;
+    const uint8_t *b[KMAX];
+    unsigned acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         const int d = lane + 64 * k;
-        sad[k] = 0.0f;
-        if (d < D) {
-            const int dd = d < dmax ? d : dmax;
-            // top-left corners of the two windows in padded coordinates
-            const uint8_t *a = (view == 0) ? Lp + (size_t)io * Wp + jo : Rp + (size_t)io * Wp + jo;
-            const uint8_t *b = (view == 0) ? Rp + (size_t)io * Wp + jo - dd : Lp + (size_t)io * Wp + jo + dd;
-            int s = 0;
-            for (int r = 0; r < side; r++)
-                for (int c = 0; c < side; c++) s += abs((int)a[r * Wp + c] - (int)b[r * Wp + c]);
-            sad[k] = (float)s;                                            // sadvalue :15-20
-        }
+        const int dd = d < dmax ? d : dmax;
+        b[k] = (view == 0) ? Rp + (size_t)io * Wp + jo - dd : Lp + (size_t)io * Wp + jo + dd;
+        acc[k] = 0;
     }
+    const int nk = (D + 63) >> 6;                                         // live 64-disparity slots (uniform)
+    if (side >= 4) {
+        // four taps per instruction: unaligned dword fetches + v_sad_u8 (sum of four |a - b| + accumulator).
+        // A row is side bytes: full dwords, then one dword ending at the row's last byte with the
+        // bytes already counted masked out of both operands (so nothing is read past the window).
+        const int nfull = side >> 2, rem = side & 3;
+        const unsigned tmask = rem ? (0xffffffffu << (8 * (4 - rem))) : 0u;
+        for (int r = 0; r < side; r++) {
+            for (int g = 0; g <= nfull; g++) {
+                if (g == nfull && !rem) break;
+                const int c0 = (g < nfull) ? 4 * g : side - 4;
+                const unsigned m = (g < nfull) ? 0xffffffffu : tmask;
+                unsigned a4;
+                __builtin_memcpy(&a4, a + r * Wp + c0, 4);
+                a4 &= m;
+#pragma unroll
+                for (int k = 0; k < KMAX; k++)
+                    if (k < nk) {
+                        unsigned b4;
+                        __builtin_memcpy(&b4, b[k] + r * Wp + c0, 4);
+                        acc[k] = __builtin_amdgcn_sad_u8(a4, b4 & m, acc[k]);
+                    }
+            }
+        }
+    } else {
+        for (int r = 0; r < side; r++)
+            for (int c = 0; c < side; c++)
+#pragma unroll
+                for (int k = 0; k < KMAX; k++)
+                    if (k < nk) acc[k] += (unsigned)abs((int)a[r * Wp + c] - (int)b[k][r * Wp + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) sad[k] = (lane + 64 * k < D) ? (float)acc[k] : 0.0f;   // sadvalue :15-20
     int out;
     if (view == 0) out = sad_optimal(sad, D, lane);
     else {                                                                // GetMinSadIndex :22-38
