@@ -18,6 +18,10 @@ namespace {
 constexpr int NT = 256;
 constexpr int KMAX = 4;        // D <= 256
 
+// wave minimum of non-negative floats (SAD sums, 65535, +inf): for v >= +0 the bit patterns order like
+// the values, so this is the DPP integer reduction (no LDS-crossbar shuffles)
+__device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_min_u32(__float_as_uint(v))); }
+
 // ---------------------------------------------------------------------------------- SAD
 // OptimalDisparity (Sad.h:40-85) over the wave-distributed vector sad[d], d = lane+64k.
 __device__ int sad_optimal(const float (&sad)[KMAX], int D, int lane)
@@ -29,10 +33,10 @@ __device__ int sad_optimal(const float (&sad)[KMAX], int D, int lane)
         const int d = lane + 64 * k;
         if (d >= 1 && d < D && lm > sad[k]) { lm = sad[k]; ld = d; }
     }
-    const float minv = wave_min_f32(lm);
+    const float minv = wave_min_nonneg(lm);
     // first d >= 1 whose value equals the minimum (if any value beat 65535)
     int cand = (lm == minv && ld != 0x7fffffff) ? ld : 0x7fffffff;
-    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+    cand = (int)wave_min_u32((unsigned)cand);
     const float best = (cand == 0x7fffffff) ? 65535.0f : (float)cand;
     // second minimum: starts at sad[0]; every entry equal to minv is skipped (:55-64)
     float ls = INFINITY;
@@ -42,7 +46,7 @@ __device__ int sad_optimal(const float (&sad)[KMAX], int D, int lane)
         if (d < D && !(minv == sad[k])) ls = fminf(ls, sad[k]);
     }
     const float s0 = __shfl(sad[0], 0, WAVE);
-    const float sec = fminf(s0, wave_min_f32(ls));
+    const float sec = fminf(s0, wave_min_nonneg(ls));
     if ((double)(sec - minv) <= 0.01) return 0;                           // :66
     if (best == 0.0f || best == (float)(D - 1)) return 0;                 // :71
     return (int)best;                                                     // :84
@@ -117,10 +121,9 @@ __global__ void __launch_bounds__(NT) k_sad(const uint8_t *__restrict__ Lp, cons
             const int d = lane + 64 * k;
             if (d < D && sad[k] < lm) { lm = sad[k]; ld = d; }
         }
-        const float m = wave_min_f32(lm);
+        const float m = wave_min_nonneg(lm);
         int cand = (lm == m) ? ld : 0x7fffffff;
-        for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
-        out = cand;
+        out = (int)wave_min_u32((unsigned)cand);
     }
     if (lane == 0) disp[p] = out;
 }
