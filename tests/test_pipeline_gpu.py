@@ -459,3 +459,29 @@ def test_aggregation_variants_agree_above_2gib(smt):
         ca.status()
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), variant
     ca.close()
+
+
+def test_aggregation_mean_is_ieee_division_on_extreme_values(smt):
+    """All aggregation variants must agree bit for bit on denormal, tiny, huge and ordinary sums alike
+    (IEEE float division of the in-order sum by the rectangle area; a reciprocal-table shortcut that
+    was tried failed exactly here, on sub-normal results)."""
+    H, W, D = 80, 160, 64
+    g = torch.Generator(device=DEV).manual_seed(11)
+    # one scale per disparity plane (a rectangle sums within a plane), from denormal to near-overflow
+    scale = torch.tensor([1e-44, 1e-41, 1e-39, 1e-38, 1e-30, 1e-3, 1.0, 3.0, 1e20, 1e34], device=DEV)
+    vol = torch.rand((H, W, D), device=DEV, generator=g) * scale[torch.arange(D, device=DEV) % 10]
+    img = ((torch.arange(H, device=DEV)[:, None] // 9 * 7 + torch.arange(W, device=DEV)[None, :] // 13 * 11) % 200
+           + torch.randint(0, 6, (H, W), device=DEV, generator=g)).to(torch.uint8)
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.ComputeArmLengths(img)
+    ref = torch.empty((H, W, D), device=DEV)
+    ca.set_variant(1)
+    ca.AggregationVertical(vol, ref)
+    out = torch.empty((H, W, D), device=DEV)
+    for variant in (4, 3, 5):
+        out.zero_()
+        ca.set_variant(variant)
+        ca.AggregationVertical(vol, out)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), variant
+    assert torch.isfinite(ref).all() and ((ref > 0) & (ref < 1e-38)).any() and (ref > 1e30).any()
+    ca.close()
