@@ -83,6 +83,19 @@ int smt_adcensus_timing(smt_adcensus *h, int enable); /* 0 off, N > 0: record ev
 int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *cost_ms, int capacity,
                               int *count);
 
+/* Measurement hook (bench.py roofline leg; not part of the reference's surface).  Needs a pair already
+ * computed on the handle and D = 64, 128, 192 or 256.  On the handle's stream it runs `reps` launches of
+ * a store-only twin of the both-views cost kernel (identical grid, chunk order and streaming stores into
+ * the handle's own volumes, no arithmetic) and then `reps` launches of the real kernel with in-kernel
+ * counter stamps, and returns
+ *   sclk_mhz       median over workgroups of d(s_memtime)/d(s_memrealtime) x 100 MHz inside the last
+ *                  stamped launch = the shader clock the cost kernel actually ran at,
+ *   cost_ms        mean duration of the stamped launches (no WTA maps are written),
+ *   store_only_ms  mean duration of the store-only launches = the store ceiling of this pattern in
+ *                  this process on these buffers.
+ * Any of the three may be NULL.  The volumes hold the last pair's costs again on return.  Synchronising. */
+int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms, float *store_only_ms);
+
 /* =====================================================================================
  * AD-Census cost volume + WTA        replaces class AD_Census, AD-CensusV1/AD-Census.h
  * ===================================================================================== */
@@ -121,8 +134,11 @@ int smt_adcensus_volume(smt_adcensus *h, int view, float **vol);
  * independent formulation kept for cross-checking) instead of the register-window kernel. */
 int smt_adcensus_force_generic(smt_adcensus *h, int on);
 
-/* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen so far was not an
- * integer in 0..255 (then the volumes are unspecified), else SMT_OK. */
+/* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen since the previous
+ * smt_adcensus_status call (or since create) was not an integer in 0..255 (then those pairs' volumes
+ * are unspecified), else SMT_OK.  Read-and-clear: a bad pair does not poison later checks.  Bad input is
+ * therefore reported late, at the first status call after the compute; call it before consuming results
+ * (the host mirrors do so in WTA() / GetPtr*()). */
 int smt_adcensus_status(smt_adcensus *h);
 
 /* First-strict-minimum argmin over d of one volume.  Replaces
@@ -166,19 +182,38 @@ int smt_crossarm_set_stream(smt_crossarm *h, void *stream);
  *   img        uint8 [H][W][channels], channels 1 (gray branch) or 3 (Vec3b branch). */
 int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels);
 
+/* One-to-one forms of the reference's four calls (CrossArm.h:15-18), for callers that run a subset or
+ * another order -- which changes the sticky-threshold chain (`_tao` is lowered at CrossArm.cpp:223-225 by
+ * whichever call first walks past sec_length and stays lowered for every later pixel and call):
+ *   smt_crossarm_reset    = the state part of Initialize (CrossArm.cpp:13-17): threshold back to tau, the
+ *                           four maps zeroed (also clears the UB flag);
+ *   smt_crossarm_arm_dir  = ComputeLeftArmLength (dir 0, :147-260), ComputeRightArmLength (1, :262-373),
+ *                           ComputeTopArmLength (2, :375-486), ComputeButtonArmLength (3, :488-598) with
+ *                           the threshold as the previous call left it;
+ *   smt_crossarm_tau      = the current `_tao` (synchronising; for tests).
+ * smt_crossarm_arms(h, img, ch) == reset + arm_dir 0, 1, 2, 3, in two launches.  With chain_tau = 0
+ * (CBLSM.h:643, by-value threshold) every call starts from tau. */
+int smt_crossarm_reset(smt_crossarm *h);
+int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channels, int dir);
+int smt_crossarm_tau(smt_crossarm *h, int *tau);
+
 /* Borrowed pointers to the int32 [H][W] arm maps (leftLength, rightLength, topLength,
  * buttonLenght; CrossArm.h:30-33). */
 int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, int **bottom);
 
 /* order 0: AggregationVertical (CrossArm.cpp:60-102), columns outer / rows inner;
- * order 1: costAggregationV5 (CBLSM.h:1179-1224), rows outer / columns inner.
+ * order 1: costAggregationV5 (CBLSM.h:1179-1224), rows outer / columns inner;
+ * order 2: Aggregation (CrossArm.cpp:104-145; public in CrossArm.h:19, no call site): rows outer with
+ *          EXCLUSIVE upper bounds [-up, down) x [-L, R); a pixel whose rectangle is empty divides 0 by 0
+ *          (:138) -- the result is NaN there and smt_crossarm_status returns SMT_ERR_REF_UB.
  * Sequential float adds in exactly that order, divided by the tap count.
  * If disp != NULL the WTA of the aggregated volume is fused (CrossArm.cpp:33-57).
  * Returns SMT_ERR_REF_UB from smt_crossarm_status when a rectangle leaves the plane
  * (possible with the right-arm stride bug on small / non-landscape images). */
 int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out, int order,
                            float *disp);
-int smt_crossarm_status(smt_crossarm *h); /* synchronising */
+int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
+                                             plane since the previous status call / reset / arms */
 /* Test / tuning hook: which aggregation kernel runs.  4 = 2x8 pixels per wave, every tap of the
  * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
  * a member skipped (default), 5 = the same without the skip, 3 = 1x8 pixels without the skip,
@@ -238,6 +273,14 @@ int smt_scanline_pass(smt_scanline *h, const float *vol_in, const float *gray, i
  * mismatches}, may be NULL. */
 int smt_lrcheck(float *dispL, const float *dispR, int H, int W, int gate, uint8_t *cls,
                 int *counts, void *stream);
+
+/* LeftAndRightConsistency (AD-CensusV1/PostProcessing.h:10-70; no call site): the out-of-place sibling.
+ * dispL is only read; lastDisp float32 [H][W] receives dispL where the pixel is kept and 0 where it is
+ * rejected; the test is abs(d - dR) >= gate with a float gate (:32), no +inf pre-check.  Classes as
+ * smt_lrcheck.  A disparity for which `static_cast<int>(j - disp + 0.5)` overflows int (non-finite or
+ * huge; undefined in C++) is treated as x86 does: INT_MIN, i.e. out of range -> mismatch. */
+int smt_lrcheck_variant(const float *dispL, const float *dispR, float *lastDisp, int H, int W, float gate,
+                        uint8_t *cls, int *counts, void *stream);
 
 /* Host helper: expand a HOST copy of cls into the reference's (row, col) pair lists.
  * Each list must have room for H*W pairs (2 ints per pair); returns counts. */

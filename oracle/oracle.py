@@ -25,9 +25,12 @@ def build(verbose=False):
 
 
 def _load():
-    if not os.path.exists(_LIB):
+    # SMT_ORACLE_OMP=1: the rows-/planes-/lines-parallel OpenMP build of the same file (identical
+    # results, independent iterations only) -- used by the fixture generator and the all-core baseline
+    path = os.path.join(_HERE, "libsmt_oracle_omp.so") if os.environ.get("SMT_ORACLE_OMP") == "1" else _LIB
+    if not os.path.exists(path):
         build()
-    return C.CDLL(_LIB)
+    return C.CDLL(path)
 
 
 _lib = None
@@ -169,6 +172,37 @@ def lrcheck(dL, dR, gate=2):
     nm = C.c_long()
     lib().orc_lrcheck(_p(dL), _p(dR), H, W, gate, _p(cls), C.byref(no), C.byref(nm))
     return dL, cls, no.value, nm.value
+
+
+def lrcheck_variant(dL, dR, gate):
+    """LeftAndRightConsistency (PostProcessing.h:10-70) -> (lastDisp, cls, n_occ, n_mis)."""
+    dL = _c(dL, np.float32)
+    dR = _c(dR, np.float32)
+    H, W = dL.shape
+    last = np.empty((H, W), np.float32)
+    cls = np.empty((H, W), np.uint8)
+    no = C.c_long()
+    nm = C.c_long()
+    lib().orc_lrcheck_variant(_p(dL), _p(dR), _p(last), H, W, C.c_float(gate), _p(cls), C.byref(no), C.byref(nm))
+    return last, cls, no.value, nm.value
+
+
+def arms_dir(img, dirn, tau, tau_low=6, sec=17, maxlen=34, right_row_bug=True, out=None):
+    """One Compute*ArmLength call (dirn 0 left, 1 right, 2 top, 3 bottom) entered with threshold `tau`;
+    returns (map, threshold afterwards).  `out`: the map to write into (the right-arm call with the
+    stride bug leaves most of it untouched); default = a zeroed map, as after Initialize."""
+    img = _c(img, np.uint8)
+    if img.ndim == 2:
+        H, W = img.shape
+        ch = 1
+    else:
+        H, W, ch = img.shape
+    if out is None:
+        out = np.zeros((H, W), np.int32)
+    t = C.c_int(tau)
+    lib().orc_arms_dir(_p(img), H, W, ch, int(dirn), C.byref(t), tau_low, sec, maxlen,
+                       int(right_row_bug and dirn == 1), _p(out))
+    return out, t.value
 
 
 # --------------------------------------------------------------------------- CrossAggregator

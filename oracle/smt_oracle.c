@@ -332,8 +332,13 @@ ORC_API long orc_aggregate_rect(const float *vol, int H, int W, int D, const int
                                 int order, float *out)
 {
     size_t n = (size_t)H * W;
-    float *plane = (float *)malloc(n * sizeof(float));
     long oob = 0;
+    /* the d-planes are independent (:66 loops over them); the OpenMP build (fixture generator
+     * only) hands them to threads, each with its own plane buffer */
+#pragma omp parallel reduction(+ : oob)
+    {
+    float *plane = (float *)malloc(n * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
     for (int d = 0; d < D; d++) {
         for (size_t p = 0; p < n; p++) plane[p] = vol[p * D + d];     /* :68-75 */
         for (int i = 0; i < H; i++)
@@ -349,7 +354,7 @@ ORC_API long orc_aggregate_rect(const float *vol, int H, int W, int D, const int
                             if (idx < 0 || idx >= (long)n) oob++; else x = plane[idx];
                             v = v + x; cnt++;                          /* :92-93 */
                         }
-                } else {
+                } else if (order == 1) {
                     for (int t = -up; t <= dn; t++)
                         for (int l = -Ll; l <= Rr; l++) {
                             long idx = (long)(i + t) * W + j + l;
@@ -357,11 +362,25 @@ ORC_API long orc_aggregate_rect(const float *vol, int H, int W, int D, const int
                             if (idx < 0 || idx >= (long)n) oob++; else x = plane[idx];
                             v = v + x; cnt++;                          /* CBLSM.h:1214-1215 */
                         }
+                } else {
+                    /* order 2: CrossArmAggregation::Aggregation, CrossArm.cpp:104-145 (declared public,
+                     * CrossArm.h:19, never called): rows outer, EXCLUSIVE upper bounds (:130-132).  An
+                     * empty rectangle divides 0.0f by 0 (:138): NaN under IEEE; counted with the
+                     * out-of-plane reads as "reference undefined". */
+                    for (int t = -up; t < dn; t++)
+                        for (int l = -Ll; l < Rr; l++) {
+                            long idx = (long)(i + t) * W + j + l;
+                            float x = 0.0f;
+                            if (idx < 0 || idx >= (long)n) oob++; else x = plane[idx];
+                            v = v + x; cnt++;                          /* :134-135 */
+                        }
+                    if (cnt == 0) oob++;
                 }
                 out[((size_t)i * W + j) * D + d] = v / (float)cnt;     /* :96-98 */
             }
     }
     free(plane);
+    }
     return oob;
 }
 
@@ -376,7 +395,10 @@ ORC_API void orc_scan_lr(const float *cost, const float *gray, int H, int W, int
 {
     float p1 = (float)p1i, p2Init = (float)p2i;                       /* :132-133 */
     int dir = is_left ? 1 : -1;
+#pragma omp parallel
+    {
     float *last = (float *)malloc((D + 2) * sizeof(float));
+#pragma omp for schedule(static)
     for (int i = 0; i < H; i++) {
         size_t x0 = is_left ? 0 : (size_t)(W - 1);
         const float *ci = cost + ((size_t)i * W + x0) * D;
@@ -410,6 +432,7 @@ ORC_API void orc_scan_lr(const float *cost, const float *gray, int H, int W, int
         }
     }
     free(last);
+    }
 }
 
 ORC_API void orc_scan_ud(const float *cost, const float *gray, int H, int W, int D,
@@ -417,8 +440,11 @@ ORC_API void orc_scan_ud(const float *cost, const float *gray, int H, int W, int
 {
     float p1 = (float)p1i, p2Init = (float)p2i;
     int dir = is_up ? 1 : -1;
-    float *last = (float *)malloc((D + 2) * sizeof(float));
     ptrdiff_t step = (ptrdiff_t)dir * W * D;
+#pragma omp parallel
+    {
+    float *last = (float *)malloc((D + 2) * sizeof(float));
+#pragma omp for schedule(static)
     for (int j = 0; j < W; j++) {
         size_t y0 = is_up ? 0 : (size_t)(H - 1);
         const float *ci = cost + (y0 * W + j) * D;
@@ -453,6 +479,7 @@ ORC_API void orc_scan_ud(const float *cost, const float *gray, int H, int W, int
         }
     }
     free(last);
+    }
 }
 
 /* ScanLine: four passes then ((left+right)+up)+down.  :104-128 */
@@ -477,6 +504,10 @@ ORC_API int orc_scanline(const float *cost, const float *gray, int H, int W, int
  *      In place on dL.  cls: 0 = kept, 1 = occlusion, 2 = mismatch (the two reference
  *      vectors are these classes listed in row-major order).
  * ---------------------------------------------------------------------------------- */
+/* x86 result of `static_cast<int>(double)` when the value does not fit (undefined in C/C++): cvttsd2si
+ * returns INT_MIN. */
+static int orc_d2i(double x) { return (x > -2147483649.0 && x < 2147483648.0) ? (int)x : (-2147483647 - 1); }
+
 ORC_API void orc_lrcheck(float *dL, const float *dR, int H, int W, int gate, uint8_t *cls,
                          long *n_occ, long *n_mis)
 {
@@ -488,11 +519,11 @@ ORC_API void orc_lrcheck(float *dL, const float *dR, int H, int W, int gate, uin
             uint8_t c = 0;
             if (*disp == INFINITY) { c = 2; }                          /* :90-93 */
             else {
-                int cr = (int)((double)((float)j - *disp) + 0.5);      /* :96 */
+                int cr = orc_d2i((double)((float)j - *disp) + 0.5);   /* :96 */
                 if (cr >= 0 && cr < W) {
                     float dr = dR[i * W + cr];
                     if (fabsf(*disp - dr) > thr) {                     /* :103 */
-                        int crl = (int)((double)((float)cr + dr) + 0.5); /* :110 */
+                        int crl = orc_d2i((double)((float)cr + dr) + 0.5); /* :110 */
                         if (crl > 0 && crl < W) {
                             float dl = dL[i * W + crl];                /* in-place read :112 */
                             c = (dl > *disp) ? 1 : 2;
@@ -501,6 +532,32 @@ ORC_API void orc_lrcheck(float *dL, const float *dR, int H, int W, int gate, uin
                     }
                 } else { *disp = INFINITY; c = 2; }                    /* :130-131 */
             }
+            cls[i * W + j] = c;
+            if (c == 1) no++; else if (c == 2) nm++;
+        }
+    *n_occ = no; *n_mis = nm;
+}
+
+/* LeftAndRightConsistency                                PostProcessing.h:10-70 (no call site)
+ *      Out of place: leftDisp is only read, lastDisp written.  cls as orc_lrcheck. */
+ORC_API void orc_lrcheck_variant(const float *dL, const float *dR, float *last, int H, int W, float gate,
+                                 uint8_t *cls, long *n_occ, long *n_mis)
+{
+    long no = 0, nm = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float disp = dL[i * W + j];
+            uint8_t c = 0;
+            int cr = orc_d2i((double)((float)j - disp) + 0.5);                  /* :24 */
+            if (cr >= 0 && cr < W) {
+                float dr = dR[i * W + cr];
+                if (fabsf(disp - dr) >= gate) {                                /* :32 */
+                    int crl = orc_d2i((double)((float)cr + dr) + 0.5);          /* :40 */
+                    if (crl > 0 && crl < W) c = (dL[i * W + crl] > disp) ? 1 : 2; /* :41-49 */
+                    else c = 2;                                                /* :51-53 */
+                    last[i * W + j] = 0;                                       /* :57 */
+                } else last[i * W + j] = disp;                                 /* :61 */
+            } else { last[i * W + j] = 0; c = 2; }                             /* :64-67 */
             cls[i * W + j] = c;
             if (c == 1) no++; else if (c == 2) nm++;
         }

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
 __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
-           "ScanlineOptimizer", "LeftRightConsistency", "CrossAggregator", "GetPointDepthLeft",
+           "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
            "to_float", "MedianFilter", "RemoveSpeckles"]
@@ -150,6 +150,13 @@ class AD_Census:
         check(lib().smt_adcensus_kernel_times(self._h, a, b, cap, C.byref(n)), "smt_adcensus_kernel_times")
         return list(a[:n.value]), list(b[:n.value])
 
+    def diag(self, reps=20):
+        """smt_adcensus_diag: (in-kernel shader clock in MHz, stamped cost-kernel ms, store-only ms)."""
+        self._bind_stream()
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        check(lib().smt_adcensus_diag(self._h, int(reps), C.byref(a), C.byref(b), C.byref(c)), "smt_adcensus_diag")
+        return a.value, b.value, c.value
+
     def close(self):
         if self._h is not None:
             lib().smt_adcensus_destroy(self._h)
@@ -217,6 +224,39 @@ class CrossArmAggregation:
         self._bind()
         check(lib().smt_crossarm_arms(self._h, _ptr(Image), ch), "smt_crossarm_arms")
 
+    def Reset(self):
+        """The state part of Initialize (CrossArm.cpp:13-17): `_tao = tao`, four zeroed maps."""
+        self._bind()
+        check(lib().smt_crossarm_reset(self._h), "smt_crossarm_reset")
+
+    def _arm_dir(self, Image, dirn):
+        ch = 1 if Image.dim() == 2 else int(Image.shape[2])
+        _dev(Image, torch.uint8, (self.row, self.col) if ch == 1 else (self.row, self.col, ch), "Image")
+        self._bind()
+        check(lib().smt_crossarm_arm_dir(self._h, _ptr(Image), ch, dirn), "smt_crossarm_arm_dir")
+
+    def ComputeLeftArmLength(self, Image):
+        """CrossArm.cpp:147-260, with the sticky threshold as the previous call left it."""
+        self._arm_dir(Image, 0)
+
+    def ComputeRightArmLength(self, Image):
+        """CrossArm.cpp:262-373 (`col = _row`, :265)."""
+        self._arm_dir(Image, 1)
+
+    def ComputeTopArmLength(self, Image):
+        """CrossArm.cpp:375-486."""
+        self._arm_dir(Image, 2)
+
+    def ComputeButtonArmLength(self, Image):
+        """CrossArm.cpp:488-598."""
+        self._arm_dir(Image, 3)
+
+    def tao(self):
+        """Current value of the member `_tao` (CrossArm.h:34)."""
+        t = C.c_int()
+        check(lib().smt_crossarm_tau(self._h, C.byref(t)), "smt_crossarm_tau")
+        return t.value
+
     def arm_maps(self):
         ps = [C.c_void_p() for _ in range(4)]
         check(lib().smt_crossarm_arm_maps(self._h, *[C.byref(p) for p in ps]), "smt_crossarm_arm_maps")
@@ -235,6 +275,11 @@ class CrossArmAggregation:
     def AggregationVertical(self, dispVolume, aggregatedCostVolume, disp=None):
         """CrossArm.cpp:60-102 (+ fused WTA :33-57 when disp is given)."""
         self._agg(dispVolume, aggregatedCostVolume, 0, disp)
+
+    def Aggregation(self, dispVolume, aggregatedCostVolume, disp=None):
+        """CrossArm.cpp:104-145 (no call site in the reference): rows outer, exclusive upper bounds; empty
+        rectangles give NaN and status() raises SMT_ERR_REF_UB."""
+        self._agg(dispVolume, aggregatedCostVolume, 2, disp)
 
     def costAggregationV5(self, dispvolume, CostVolume, disp=None):
         """CBLSM.h:1179-1224 (row-major add order)."""
@@ -394,6 +439,20 @@ def LeftRightConsistency(col, row, gate, leftDisp, rightDisp, want_lists=False):
     check(lib().smt_lrcheck_lists(ch.ctypes.data_as(C.c_void_p), row, col, occ.ctypes.data_as(C.c_void_p),
                                   C.byref(no), mis.ctypes.data_as(C.c_void_p), C.byref(nm)), "smt_lrcheck_lists")
     return cls, n[0], n[1], occ[:no.value], mis[:nm.value]
+
+
+def LeftAndRightConsistency(leftDisp, rightDisp, lastDisp, col, row, gate):
+    """PostProcessing.h:10-70 (argument order of the reference; no call site there): out of place, lastDisp
+    receives the kept disparities and 0 for rejected pixels.  Returns (cls, n_occlusion, n_mismatch)."""
+    _dev(leftDisp, torch.float32, (row, col), "leftDisp")
+    _dev(rightDisp, torch.float32, (row, col), "rightDisp")
+    _dev(lastDisp, torch.float32, (row, col), "lastDisp")
+    cls = torch.empty((row, col), dtype=torch.uint8, device=leftDisp.device)
+    counts = torch.zeros(2, dtype=torch.int32, device=leftDisp.device)
+    check(lib().smt_lrcheck_variant(_ptr(leftDisp), _ptr(rightDisp), _ptr(lastDisp), row, col, C.c_float(gate),
+                                    _ptr(cls), _ptr(counts), current_stream_ptr()), "smt_lrcheck_variant")
+    n = counts.cpu().tolist()
+    return cls, n[0], n[1]
 
 
 def FillTheHole(row, col, dispRange, dispLeft, occlusion, mismatch):

@@ -24,6 +24,7 @@
 // LDS once per workgroup; WTA is a wave min + ballot (first strict minimum, :355-373).
 #include "smt_common.h"
 #include <math.h>
+#include <algorithm>
 #include <new>
 #include <type_traits>
 
@@ -41,6 +42,7 @@ struct Tables {
     float *lut;          // 256 + 64 floats
     int *flag;           // domain flag
     int WX;
+    unsigned long long *stamp;   // diagnostics only (smt_adcensus_diag): 4 counters per workgroup, else null
 };
 
 // ---- tap validity mask + the four census tables --------------------------------------
@@ -556,8 +558,43 @@ __global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T
 {
     int view, i, bx;
     if (!chunk_of_block(nbx, H, 2, view, i, bx)) return;
+    // diagnostic launches only (T.stamp != null, smt_adcensus_diag): the shader-clock and the 100 MHz
+    // real-time counters around the first wave's work; their ratio is the clock the kernel ran at
+    // (MI355X_MICROARCH.md, DVFS item 6).  Ordinary launches take the null branch and execute no stamp.
+    unsigned long long t0 = 0, r0 = 0;
+    if (T.stamp) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (view == 0) cost_fast_body<C, 0, FULL>(H, W, D, T, vol0, disp0, i, bx);
     else cost_fast_body<C, 1, FULL>(H, W, D, T, vol1, disp1, i, bx);
+    if (T.stamp && threadIdx.x == 0) {
+        unsigned long long *s = T.stamp + 4 * (size_t)blockIdx.x;
+        s[0] = t0; s[1] = r0; s[2] = __builtin_amdgcn_s_memtime(); s[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Store-only twin of k_cost_fast2<C, true>: the same grid, workgroup -> chunk order and streaming stores
+// of 64*C*4 bytes per pixel-wave, no tables, no arithmetic.  What it reaches on the handle's own volumes
+// is the ceiling the memory system gives this store pattern in this process (smt_adcensus_diag).
+template <int C>
+__global__ void __launch_bounds__(NT) k_store_only2(int H, int W, float *__restrict__ vol0,
+                                                    float *__restrict__ vol1, int nbx)
+{
+    constexpr int D = 64 * C;
+    int view, i, bx;
+    if (!chunk_of_block(nbx, H, 2, view, i, bx)) return;
+    float *vol = view ? vol1 : vol0;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = bx * FTJ, p0 = wid * FPW;
+    const int npx = min(FPW, W - (j0 + p0));
+    float *out = vol + ((size_t)i * W + j0 + p0) * D + lane * C;
+    float x[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) x[k] = (float)(lane + k);
+    for (int q = 0; q < npx; q++) {
+        st_stream<C>(out, x);
+        out += D;
+        x[0] += 1.0f;
+    }
 }
 
 // WTA over an existing volume: one wave per pixel, lane owns C consecutive d (one vector load when
@@ -580,12 +617,7 @@ __global__ void __launch_bounds__(NT) k_wta(const float *__restrict__ vol, int N
 #pragma unroll
         for (int k = 0; k < C; k++) v[k] = (dl + k < D) ? c[k] : INFINITY;
     }
-    float best = v[0]; int bd = dl;
-#pragma unroll
-    for (int k = 1; k < C; k++)
-        if ((FULL || dl + k < D) && best > v[k]) { best = v[k]; bd = dl + k; }
-    if (!FULL && dl >= D) best = INFINITY;
-    const int wd = wave_argmin_first(best, bd);
+    const int wd = wave_wta<C, FULL>(v, dl, D);
     if (lane == 0) disp[p] = (float)wd;
 }
 
@@ -686,6 +718,7 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     alloc((void **)&h->TS[0].flag, 4);
     for (int t = 0; t < 2; t++) {
         h->TS[t].WX = WX;
+        h->TS[t].stamp = nullptr;
         h->TS[t].lut = h->TS[0].lut;                     // shared
         h->TS[t].flag = h->TS[0].flag;
         for (int v = 0; v < 2; v++) {
@@ -892,6 +925,7 @@ SMT_API int smt_adcensus_status(smt_adcensus *h)
     if (!h) return SMT_ERR_ARG;
     int f = 0;
     SMT_HIP(hipMemcpyAsync(&f, h->T.flag, 4, hipMemcpyDeviceToHost, h->stream));
+    SMT_HIP(hipMemsetAsync(h->T.flag, 0, 4, h->stream));            // read-and-clear
     SMT_HIP(hipStreamSynchronize(h->stream));
     return f ? SMT_ERR_DOMAIN : SMT_OK;
 }
@@ -939,6 +973,70 @@ SMT_API int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *co
         if (cost_ms) cost_ms[k] = b;
     }
     *count = (int)n;
+    return SMT_OK;
+}
+
+// Measurement hook (bench.py): see include/smt.h.
+SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms,
+                              float *store_only_ms)
+{
+    if (!h || reps <= 0 || reps > 1000) return SMT_ERR_ARG;
+    if (h->n_pairs == 0) return SMT_ERR_STATE;               // needs the tables of a computed pair
+    const int D = h->D, C = D / 64;
+    if (D % 64 != 0 || C < 1 || C > 4) return SMT_ERR_ARG;
+    const int nbx = (h->W + FTJ - 1) / FTJ;
+    const unsigned nblk = (unsigned)(((long)nbx * h->H * 2 + 7) / 8 * 8);
+    hipEvent_t e[3];
+    for (auto &x : e) SMT_HIP(hipEventCreate(&x));
+    unsigned long long *stamp = nullptr;
+    if (smt_malloc((void **)&stamp, (size_t)nblk * 32) != SMT_OK) return SMT_ERR_ALLOC;
+    SMT_HIP(hipMemsetAsync(stamp, 0, (size_t)nblk * 32, h->stream));
+    Tables T = h->T;
+    T.stamp = stamp;
+    SMT_HIP(hipEventRecord(e[0], h->stream));
+    for (int r = 0; r < reps; r++) {
+        switch (C) {
+        case 1: hipLaunchKernelGGL((k_store_only2<1>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, h->vol[0], h->vol[1], nbx); break;
+        case 2: hipLaunchKernelGGL((k_store_only2<2>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, h->vol[0], h->vol[1], nbx); break;
+        case 3: hipLaunchKernelGGL((k_store_only2<3>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, h->vol[0], h->vol[1], nbx); break;
+        default: hipLaunchKernelGGL((k_store_only2<4>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, h->vol[0], h->vol[1], nbx); break;
+        }
+    }
+    SMT_HIP(hipEventRecord(e[1], h->stream));
+    // the real kernel with stamps, last, so that the volumes hold the pair's costs again afterwards
+    for (int r = 0; r < reps; r++) {
+        switch (C) {
+        case 1: hipLaunchKernelGGL((k_cost_fast2<1, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
+        case 2: hipLaunchKernelGGL((k_cost_fast2<2, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
+        case 3: hipLaunchKernelGGL((k_cost_fast2<3, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
+        default: hipLaunchKernelGGL((k_cost_fast2<4, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
+        }
+    }
+    SMT_HIP(hipEventRecord(e[2], h->stream));
+    SMT_LAUNCH_CHECK();
+    SMT_HIP(hipEventSynchronize(e[2]));
+    float a = 0, b = 0;
+    SMT_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+    SMT_HIP(hipEventElapsedTime(&b, e[1], e[2]));
+    if (store_only_ms) *store_only_ms = a / reps;
+    if (cost_ms) *cost_ms = b / reps;
+    if (sclk_mhz) {
+        // stamps of the last launch: median over workgroups of d(s_memtime) / d(s_memrealtime) * 100 MHz
+        unsigned long long *hs = new (std::nothrow) unsigned long long[(size_t)nblk * 4];
+        float *ratio = new (std::nothrow) float[nblk];
+        if (!hs || !ratio) { delete[] hs; delete[] ratio; (void)hipFree(stamp); return SMT_ERR_ALLOC; }
+        SMT_HIP(hipMemcpy(hs, stamp, (size_t)nblk * 32, hipMemcpyDeviceToHost));
+        size_t n = 0;
+        for (unsigned k = 0; k < nblk; k++) {
+            const unsigned long long dt = hs[4 * k + 2] - hs[4 * k], dr = hs[4 * k + 3] - hs[4 * k + 1];
+            if (hs[4 * k + 3] != 0 && dr >= 200) ratio[n++] = (float)((double)dt / (double)dr * 100.0);
+        }
+        if (n) { std::nth_element(ratio, ratio + n / 2, ratio + n); *sclk_mhz = ratio[n / 2]; }
+        else *sclk_mhz = 0.0f;
+        delete[] hs; delete[] ratio;
+    }
+    for (auto &x : e) (void)hipEventDestroy(x);
+    SMT_HIP(hipFree(stamp));
     return SMT_OK;
 }
 

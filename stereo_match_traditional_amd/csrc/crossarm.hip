@@ -59,9 +59,14 @@ __device__ __forceinline__ bool arm_nb(int dir, int i, int j, int k, int H, int 
     }
 }
 
-__global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img, ArmCfg c, int *flip)
+// tau_state: the threshold as the previous call left it (`_tao`, CrossArm.h:34).  The fused four-direction
+// call resets it first and derives the chaining from flip[0..dir-1] (prev_flips = 1); the one-direction
+// calls (dir0 = that direction, gridDim.y = 1, prev_flips = 0) read it here and k_tau_update advances it.
+__global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img, ArmCfg c, int *flip, int dir0,
+                                                 const int *__restrict__ tau_state)
 {
-    const int dir = blockIdx.y;
+    const int dir = dir0 + blockIdx.y;
+    if (*tau_state != c.tau) return;                    // already lowered: no flip left to find
     const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
     const int idx = blockIdx.x * NT + threadIdx.x;
     // only the smallest qualifying index matters: workgroups behind a candidate already found have
@@ -85,16 +90,17 @@ __global__ void __launch_bounds__(NT) k_arm_flip(const uint8_t *__restrict__ img
 
 __global__ void __launch_bounds__(NT) k_arms(const uint8_t *__restrict__ img, ArmCfg c,
                                              const int *__restrict__ flip, int *armL, int *armR,
-                                             int *armT, int *armB)
+                                             int *armT, int *armB, int dir0, int prev_flips,
+                                             const int *__restrict__ tau_state)
 {
-    const int dir = blockIdx.y;
+    const int dir = dir0 + blockIdx.y;
     const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
     const int idx = blockIdx.x * NT + threadIdx.x;
     if (idx >= c.H * colR) return;
     const int i = idx / colR, j = idx - i * colR;
 
-    int tau_in = c.tau;
-    if (c.chain)
+    int tau_in = *tau_state;
+    if (c.chain && prev_flips)
         for (int e = 0; e < dir; e++)
             if (flip[e] != INT_MAX) tau_in = c.tau_low;
     const int F = flip[dir];
@@ -122,6 +128,14 @@ __global__ void __launch_bounds__(NT) k_arms(const uint8_t *__restrict__ img, Ar
     }
     int *out = dir == 0 ? armL : dir == 1 ? armR : dir == 2 ? armT : armB;
     out[(size_t)i * colR + j] = saved;
+}
+
+// after the direction(s) dir0 .. dir0+ndir-1: a member threshold (chain) that flipped stays lowered
+__global__ void k_tau_update(const int *__restrict__ flip, int dir0, int ndir, int chain, int tau_low, int *tau_state)
+{
+    if (!chain) return;
+    for (int e = dir0; e < dir0 + ndir; e++)
+        if (flip[e] != INT_MAX) *tau_state = tau_low;
 }
 
 template <int C> struct vecf;
@@ -169,25 +183,27 @@ __global__ void __launch_bounds__(NT) k_aggregate(const float *__restrict__ vin,
     if (ORDER == 0) {
         for (int l = -Ll; l <= Rr; l++)
             for (int t = -up; t <= dn; t++) tap(t, l);
-    } else {
+    } else if (ORDER == 1) {
         for (int t = -up; t <= dn; t++)
             for (int l = -Ll; l <= Rr; l++) tap(t, l);
+    } else {
+        // CrossArmAggregation::Aggregation (CrossArm.cpp:104-145, no call site): rows outer, EXCLUSIVE
+        // upper bounds (:130-132); a pixel with Ll+Rr == 0 or up+dn == 0 divides 0 by 0 (:138) -> NaN,
+        // reported as reference-undefined
+        for (int t = -up; t < dn; t++)
+            for (int l = -Ll; l < Rr; l++) tap(t, l);
     }
-    const float cnt = (float)((Ll + Rr + 1) * (up + dn + 1));
-    float best = INFINITY; int bk = 0;
+    const float cnt = (ORDER == 2) ? (float)((Ll + Rr) * (up + dn)) : (float)((Ll + Rr + 1) * (up + dn + 1));
+    if (ORDER == 2 && cnt == 0.0f) ub = true;
     float *dst = vout + (size_t)p * D + dl;
 #pragma unroll
     for (int k = 0; k < C; k++) {
         acc[k] = acc[k] / cnt;
-        if (dl + k < D) {
-            dst[k] = acc[k];
-            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
-        }
+        if (dl + k < D) dst[k] = acc[k];
     }
     if (ub && lane == 0) atomicOr(ub_flag, 1);
     if (disp) {
-        if (dl >= D) best = INFINITY;
-        const int wd = wave_argmin_first(best, dl + bk);
+        const int wd = wave_wta<C, false>(acc, dl, D);
         if (lane == 0) disp[p] = (float)wd;
     }
 }
@@ -298,20 +314,15 @@ __global__ void __launch_bounds__(NT) k_aggregate_pipe(const float *__restrict__
         }
     }
     const float cnt = (float)total;
-    float best = INFINITY; int bk = 0;
     float *dst = vout + (size_t)p * D + dl;
 #pragma unroll
     for (int k = 0; k < C; k++) {
         acc[k] = acc[k] / cnt;
-        if (FULL || dl + k < D) {
-            dst[k] = acc[k];
-            if (k == 0 || best > acc[k]) { best = acc[k]; bk = k; }
-        }
+        if (FULL || dl + k < D) dst[k] = acc[k];
     }
     if (ub && lane == 0) atomicOr(ub_flag, 1);
     if (disp) {
-        if (!FULL && dl >= D) best = INFINITY;
-        const int wd = wave_argmin_first(best, dl + bk);
+        const int wd = wave_wta<C, FULL>(acc, dl, D);
         if (lane == 0) disp[p] = (float)wd;
     }
 }
@@ -471,19 +482,15 @@ __global__ void __launch_bounds__(NT) k_aggregate_quad(const float *__restrict__
     for (int q = 0; q < QP; q++) {
         if (q >= nlive) continue;
         const float fc = (float)cnt[q];
-        float best = INFINITY; int bk = 0;
         float *dst = vout + (size_t)(p0 + q) * D + dl;
+        float mean[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const float v = acc[q][k] / fc;
-            if (FULL || dl + k < D) {
-                dst[k] = v;
-                if (k == 0 || best > v) { best = v; bk = k; }
-            }
+            mean[k] = acc[q][k] / fc;
+            if (FULL || dl + k < D) dst[k] = mean[k];
         }
         if (disp) {
-            if (!FULL && dl >= D) best = INFINITY;
-            const int wd = wave_argmin_first(best, dl + bk);
+            const int wd = wave_wta<C, FULL>(mean, dl, D);
             if (lane == 0) disp[p0 + q] = (float)wd;
         }
     }
@@ -706,22 +713,18 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
     auto finish = [&](int q, const float (&a)[C]) {
         const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q), bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
         const float fc = (float)(((int)(bo >> 16) - (int)(bo & 0xffffu) + 1) * ((int)(bi >> 16) - (int)(bi & 0xffffu) + 1));
-        float best = INFINITY; int bk = 0;
         const int p = p0 + (q >> 3) * W + (q & 7);
         float *dst = vout + (size_t)p * D + dl;
+        float mean[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const float v = a[k] / fc;
-            if (FULL || dl + k < D) {
-                // streaming store: the output is not read by this kernel and would otherwise evict input
-                // taps from L2
-                __builtin_nontemporal_store(v, dst + k);
-                if (k == 0 || best > v) { best = v; bk = k; }
-            }
+            mean[k] = a[k] / fc;
+            // streaming store: the output is not read by this kernel and would otherwise evict input
+            // taps from L2
+            if (FULL || dl + k < D) __builtin_nontemporal_store(mean[k], dst + k);
         }
         if (disp) {
-            if (!FULL && dl >= D) best = INFINITY;
-            const int wd = wave_argmin_first(best, dl + bk);
+            const int wd = wave_wta<C, FULL>(mean, dl, D);
             if (lane == 0) disp[p] = (float)wd;
         }
     };
@@ -845,7 +848,7 @@ struct smt_crossarm {
     smt_crossarm_params P;
     hipStream_t stream;
     int *arm[4];
-    int *flip;     // 4 flip indices + 1 UB flag
+    int *flip;     // 4 flip indices + 1 UB flag + the sticky threshold (`_tao`) as the last call left it
     bool have_arms;
     int variant;         // aggregation kernel variant (test / tuning hook)
     int strip_w;         // column-strip width of the XCD-aware pixel order (variants 0 and 2)
@@ -879,6 +882,10 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->member, MEMBER_TAB_FLOATS * 4);
     if (rc != SMT_OK) { smt_crossarm_destroy(h); return rc; }
     if (hipMemset(h->flip, 0, 32) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
+    // Initialize (CrossArm.cpp:6-18): `_tao = tao` and four value-initialised (zero) maps
+    for (int k = 0; k < 4; k++)
+        if (hipMemset(h->arm[k], 0, (size_t)H * W * 4) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
+    if (hipMemcpy(h->flip + 5, &h->P.tau, 4, hipMemcpyHostToDevice) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
     {
         float tab[MEMBER_TAB_FLOATS];
         for (int m = 0; m < 256; m++)
@@ -906,6 +913,21 @@ SMT_API int smt_crossarm_set_stream(smt_crossarm *h, void *s)
     return SMT_OK;
 }
 
+static const int kFlipInit[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+
+SMT_API int smt_crossarm_reset(smt_crossarm *h)
+{
+    if (!h) return SMT_ERR_ARG;
+    const size_t N = (size_t)h->H * h->W;
+    // `new int[col*row]()` zero-initialises every map on each Initialize (CrossArm.cpp:14-17);
+    // with the stride bug most of rightLength stays 0.
+    for (int k = 0; k < 4; k++) SMT_HIP(hipMemsetAsync(h->arm[k], 0, N * 4, h->stream));
+    SMT_HIP(hipMemcpyAsync(h->flip + 5, &h->P.tau, 4, hipMemcpyHostToDevice, h->stream));   // `_tao = tao` (:13)
+    SMT_HIP(hipMemsetAsync(h->flip + 4, 0, 4, h->stream));                                   // UB flag of the last cycle
+    h->have_arms = true;
+    return SMT_OK;
+}
+
 SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
 {
     if (!h || !img || (channels != 1 && channels != 3)) return SMT_ERR_ARG;
@@ -916,17 +938,45 @@ SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
     ArmCfg c{h->H, h->W, channels, h->P.tau, h->P.tau_low, h->P.sec_length, h->P.max_length,
              h->P.chain_tau, fix ? 1 : 0};
     const size_t N = (size_t)h->H * h->W;
-    // `new int[col*row]()` zero-initialises every map on each Initialize (CrossArm.cpp:14-17);
-    // with the stride bug most of rightLength stays 0.
-    for (int k = 0; k < 4; k++) SMT_HIP(hipMemsetAsync(h->arm[k], 0, N * 4, h->stream));
-    static const int init[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
-    SMT_HIP(hipMemcpyAsync(h->flip, init, 16, hipMemcpyHostToDevice, h->stream));
+    int rc = smt_crossarm_reset(h);
+    if (rc != SMT_OK) return rc;
+    SMT_HIP(hipMemcpyAsync(h->flip, kFlipInit, 16, hipMemcpyHostToDevice, h->stream));
     dim3 grid((unsigned)((N + NT - 1) / NT), 4);
-    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip);
+    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip, 0, h->flip + 5);
     hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
-                       h->arm[2], h->arm[3]);
+                       h->arm[2], h->arm[3], 0, 1, h->flip + 5);
+    hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(1), 0, h->stream, h->flip, 0, 4, h->P.chain_tau, h->P.tau_low,
+                       h->flip + 5);
     SMT_LAUNCH_CHECK();
     h->have_arms = true;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channels, int dir)
+{
+    if (!h || !img || (channels != 1 && channels != 3) || dir < 0 || dir > 3) return SMT_ERR_ARG;
+    const bool fix = (h->P.quirks & SMT_QUIRK_FIX_RIGHT_ARM_STRIDE) != 0;
+    if (dir == 1 && !fix && h->H > h->W) return SMT_ERR_REF_UB;
+    ArmCfg c{h->H, h->W, channels, h->P.tau, h->P.tau_low, h->P.sec_length, h->P.max_length,
+             h->P.chain_tau, fix ? 1 : 0};
+    const size_t N = (size_t)h->H * h->W;
+    SMT_HIP(hipMemcpyAsync(h->flip + dir, kFlipInit, 4, hipMemcpyHostToDevice, h->stream));
+    dim3 grid((unsigned)((N + NT - 1) / NT), 1);
+    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip, dir, h->flip + 5);
+    hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
+                       h->arm[2], h->arm[3], dir, 0, h->flip + 5);
+    hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(1), 0, h->stream, h->flip, dir, 1, h->P.chain_tau, h->P.tau_low,
+                       h->flip + 5);
+    SMT_LAUNCH_CHECK();
+    h->have_arms = true;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_tau(smt_crossarm *h, int *tau)
+{
+    if (!h || !tau) return SMT_ERR_ARG;
+    SMT_HIP(hipMemcpyAsync(tau, h->flip + 5, 4, hipMemcpyDeviceToHost, h->stream));
+    SMT_HIP(hipStreamSynchronize(h->stream));
     return SMT_OK;
 }
 
@@ -1045,7 +1095,7 @@ static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *di
 
 SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vout, int order, float *disp)
 {
-    if (!h || !vin || !vout || vin == vout || (order != 0 && order != 1)) return SMT_ERR_ARG;
+    if (!h || !vin || !vout || vin == vout || order < 0 || order > 2) return SMT_ERR_ARG;
     if (!h->have_arms) return SMT_ERR_STATE;
     // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership
     // flags, groups of 4 pixels without a member skipped (default); 5 = the same without the skip;
@@ -1055,6 +1105,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     // byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
+    if (order == 2) { launch_agg<2>(h, vin, vout, disp); SMT_LAUNCH_CHECK(); return SMT_OK; }   // inactive sibling: plain walk only
     if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
     else if (variant == 3) { if (order == 0) launch_agg_multi<0, 1, 0>(h, vin, vout, disp); else launch_agg_multi<1, 1, 0>(h, vin, vout, disp); }
@@ -1084,6 +1135,7 @@ SMT_API int smt_crossarm_status(smt_crossarm *h)
     if (!h) return SMT_ERR_ARG;
     int f = 0;
     SMT_HIP(hipMemcpyAsync(&f, h->flip + 4, 4, hipMemcpyDeviceToHost, h->stream));
+    SMT_HIP(hipMemsetAsync(h->flip + 4, 0, 4, h->stream));          // read-and-clear: reports what happened since the last call
     SMT_HIP(hipStreamSynchronize(h->stream));
     return f ? SMT_ERR_REF_UB : SMT_OK;
 }

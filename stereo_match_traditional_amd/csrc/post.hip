@@ -9,17 +9,25 @@
 // pixel from the original maps, recomputing "was pixel crl rejected" on the fly for
 // crl < j; kernel 2 writes the +inf values.
 #include "smt_common.h"
+#include <limits.h>
 
 namespace {
 
 constexpr int NT = 256;
+
+// x86 result of the reference's `static_cast<int>(double)`: cvttsd2si returns INT_MIN ("integer
+// indefinite") when the value does not fit; the device conversion would saturate instead.
+__device__ __forceinline__ int d2i_x86(double x)
+{
+    return (x > -2147483649.0 && x < 2147483648.0) ? (int)x : INT_MIN;
+}
 
 // true when the reference sets leftDisp[i][x] = inf (or it already was inf)
 __device__ __forceinline__ bool lr_rejected(const float *dL, const float *dR, int row0, int x, int W, float thr)
 {
     const float d = dL[row0 + x];
     if (d == INFINITY) return true;                                       // :90
-    const int cr = (int)((double)((float)x - d) + 0.5);                   // :96
+    const int cr = d2i_x86((double)((float)x - d) + 0.5);                // :96
     if (cr >= 0 && cr < W) return fabsf(d - dR[row0 + cr]) > thr;         // :103
     return true;                                                          // :128-131
 }
@@ -42,11 +50,11 @@ __global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL
         uint8_t c = 0;
         if (d == INFINITY) c = 2;
         else {
-            const int cr = (int)((double)((float)j - d) + 0.5);
+            const int cr = d2i_x86((double)((float)j - d) + 0.5);
             if (cr >= 0 && cr < W) {
                 const float dr = dR[row0 + cr];
                 if (fabsf(d - dr) > thr) {
-                    const int crl = (int)((double)((float)cr + dr) + 0.5);    // :110
+                    const int crl = d2i_x86((double)((float)cr + dr) + 0.5); // :110
                     if (crl > 0 && crl < W) {
                         float dl = dL[row0 + crl];
                         if (crl < j && lr_rejected(dL, dR, row0, crl, W, thr)) dl = INFINITY;
@@ -56,6 +64,45 @@ __global__ void __launch_bounds__(NT) k_lr_classify(const float *__restrict__ dL
             } else c = 2;
         }
         cls[p] = c;
+        n1 += (c == 1); n2 += (c == 2);
+    }
+    if (counts) {
+        if (n1) atomicAdd(&s_cnt[0], n1);
+        if (n2) atomicAdd(&s_cnt[1], n2);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (s_cnt[0]) atomicAdd(&counts[0], s_cnt[0]);
+            if (s_cnt[1]) atomicAdd(&counts[1], s_cnt[1]);
+        }
+    }
+}
+
+// LeftAndRightConsistency (PostProcessing.h:10-70): out of place, so every pixel is independent.
+__global__ void __launch_bounds__(NT) k_lr_variant(const float *__restrict__ dL, const float *__restrict__ dR,
+                                                   float *__restrict__ last, int H, int W, float gate,
+                                                   uint8_t *__restrict__ cls, int *counts)
+{
+    __shared__ int s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = H * W;
+    int n1 = 0, n2 = 0;
+    for (int p = blockIdx.x * NT + threadIdx.x; p < n; p += gridDim.x * NT) {
+        const int i = p / W, j = p - i * W;
+        const int row0 = i * W;
+        const float d = dL[p];
+        uint8_t c = 0;
+        const int cr = d2i_x86((double)((float)j - d) + 0.5);                 // :24
+        if (cr >= 0 && cr < W) {
+            const float dr = dR[row0 + cr];
+            if (fabsf(d - dr) >= gate) {                                      // :32
+                const int crl = d2i_x86((double)((float)cr + dr) + 0.5);      // :40
+                if (crl > 0 && crl < W) c = (dL[row0 + crl] > d) ? 1 : 2;     // :41-49
+                else c = 2;
+            }
+        } else c = 2;                                                         // :64-66
+        cls[p] = c;
+        last[p] = c ? 0.0f : d;                                               // :56, :60, :65
         n1 += (c == 1); n2 += (c == 2);
     }
     if (counts) {
@@ -114,6 +161,19 @@ SMT_API int smt_lrcheck(float *dL, const float *dR, int H, int W, int gate, uint
     const int blocks = (n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048;
     hipLaunchKernelGGL(k_lr_classify, dim3(blocks), dim3(NT), 0, st, dL, dR, H, W, (float)gate, cls, counts);
     hipLaunchKernelGGL(k_lr_apply, dim3((n + NT - 1) / NT), dim3(NT), 0, st, dL, cls, n);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_lrcheck_variant(const float *dL, const float *dR, float *last, int H, int W, float gate,
+                                uint8_t *cls, int *counts, void *stream)
+{
+    if (!dL || !dR || !last || !cls || H <= 0 || W <= 0 || last == dL) return SMT_ERR_ARG;
+    hipStream_t st = smt_stream(stream);
+    const int n = H * W;
+    if (counts) SMT_HIP(hipMemsetAsync(counts, 0, 8, st));
+    const int blocks = (n + NT - 1) / NT < 2048 ? (n + NT - 1) / NT : 2048;
+    hipLaunchKernelGGL(k_lr_variant, dim3(blocks), dim3(NT), 0, st, dL, dR, last, H, W, gate, cls, counts);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }

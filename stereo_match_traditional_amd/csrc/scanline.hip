@@ -129,12 +129,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, float *out, int lin
     const float p1 = a.p1;
 
     auto wta_store = [&](const float (&res)[C], long pix) {
-        float best = INFINITY; int bk = 0;
-#pragma unroll
-        for (int k = 0; k < C; k++)
-            if ((FULL || dl + k < D) && (k == 0 || best > res[k])) { best = res[k]; bk = k; }
-        if (!FULL && dl >= D) best = INFINITY;
-        const int wd = wave_argmin_first(best, dl + bk);
+        const int wd = wave_wta<C, FULL>(res, dl, D);
         if (lane == 0) a.disp[pix] = (float)wd;
     };
 

@@ -61,11 +61,35 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     v = min(v, dpp_u32<0x143, 0xC>(v));   // row_bcast31 into rows 2,3 -> lane 63 holds the min
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-// order-preserving map float -> uint32 (handles negatives; NaNs are not ordered)
+// order-preserving map float -> uint32 (handles negatives; NaNs are not ordered -- wave_wta gives them
+// the reference's semantics)
 __device__ __forceinline__ unsigned f32_key(float f)
 {
     const unsigned b = __float_as_uint(f + 0.0f);          // -0 -> +0 so that equal zeros tie
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// WTA of one pixel held by a wave (lane l owns the C hypotheses dl = l*C .. l*C+C-1; elements at or past
+// D are ignored), with the reference's exact rule (CrossArm.cpp:44-52, ScanlineOptimizer.h:51-59,
+// AD-Census.h:355-373): `cost = vol[0]; for d >= 1: if (cost > vol[d]) { cost = vol[d]; best = d; }`.
+// A NaN never satisfies `cost > value`, so a NaN entry never wins, and a NaN at d = 0 freezes the
+// result at 0 (every later comparison against it is false).  NaN keys sort above +inf; -0 ties +0.
+template <int C, bool FULL>
+__device__ __forceinline__ int wave_wta(const float (&v)[C], int dl, int D)
+{
+    unsigned best = 0xFFFFFFFFu; int bk = 0;
+#pragma unroll
+    for (int k = 0; k < C; k++)
+        if (FULL || dl + k < D) {
+            const unsigned key = (v[k] != v[k]) ? 0xFFFFFFFFu : f32_key(v[k]);
+            if (k == 0 || key < best) { best = key; bk = k; }
+        }
+    const unsigned m = wave_min_u32(best);
+    const unsigned long long b = __ballot(best == m);
+    const int first = __builtin_ctzll(b);
+    const int wd = __builtin_amdgcn_readlane(dl + bk, first);
+    const int nan0 = __builtin_amdgcn_readlane((int)(v[0] != v[0]), 0);   // lane 0 owns d = 0
+    return nan0 ? 0 : wd;
 }
 
 // First-strict-minimum WTA across a wave whose lanes hold candidates in increasing-d

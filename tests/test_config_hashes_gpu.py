@@ -1,0 +1,136 @@
+"""BASELINE.json configs 2, 3 and 5 at FULL size: every volume and map of the HIP path (through the
+C ABI) hashed on the host (D2H + the oracle's FNV-1a) and compared with tests/golden/config_hashes.json,
+which the CPU oracle produced in the build container (tests/golden/make_config_hashes.py) on the same
+SURVEY 8(d) synthetic pairs.  This is where the up/down scanline passes (ScanlineOptimizer.h:194-253, with
+their three quirks), the ((left+right)+up)+down sum (:124), the right-view aggregation (stride-bug arms,
+CrossArm.cpp:60-102, :265) and the LR check (PostProcessing.h:72-135) are compared at 1920x1080x192.
+
+Oracle status for these stages: parity unpinned (oracle/smt_oracle.c header) -- the fixtures pin the HIP
+path to the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_hashes.json")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    assert os.path.exists(GOLD), "tests/golden/config_hashes.json missing (tests/golden/make_config_hashes.py)"
+    return json.load(open(GOLD))
+
+
+def hx(O, t):
+    a = t.cpu().numpy() if isinstance(t, torch.Tensor) else t
+    return "%016x" % O.fnv1a(a)
+
+
+def check(O, rec, key, t):
+    got = hx(O, t)
+    assert got == rec[key], f"{key}: device {got} != oracle fixture {rec[key]}"
+
+
+def test_config2_full_size_hashes(smt, O, gold):
+    from stereo_match_traditional_amd import synth
+    rec = gold["cfg2_adcensus_720p_d128"]
+    H, W, D = rec["H"], rec["W"], rec["D"]
+    L, R = synth.synth_pair(H, W, D, rec["seed"])
+    adc = smt.AD_Census().Initialize(T(L.astype(np.float32)), T(R.astype(np.float32)), D, H, W, rec["sigmaC"],
+                                     rec["sigmaS"])
+    dl = torch.empty((H, W), device=DEV)
+    dr = torch.empty((H, W), device=DEV)
+    adc.ComputeBoth(dl, dr)
+    adc.status()
+    check(O, rec, "adcensus_vol_left", adc.GetPtrLeft())
+    check(O, rec, "adcensus_vol_right", adc.GetPtrRight())
+    check(O, rec, "adcensus_disp_left", dl)
+    check(O, rec, "adcensus_disp_right", dr)
+    adc.close()
+
+
+def test_config3_full_size_hashes(smt, O, gold):
+    """The north-star pipeline in main.cpp's order (AD-CensusV1/main.cpp:59-92), every stage's output."""
+    from stereo_match_traditional_amd import synth
+    rec = gold["cfg3_pipeline_1080p_d192"]
+    H, W, D = rec["H"], rec["W"], rec["D"]
+    L, R = synth.synth_pair(H, W, D, rec["seed"])
+    Lf, Rf = T(L.astype(np.float32)), T(R.astype(np.float32))
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, rec["sigmaC"], rec["sigmaS"])
+    dl = torch.empty((H, W), device=DEV)
+    dr = torch.empty((H, W), device=DEV)
+    adc.ComputeBoth(dl, dr)
+    adc.status()
+    check(O, rec, "adcensus_vol_left", adc.GetPtrLeft())
+    check(O, rec, "adcensus_vol_right", adc.GetPtrRight())
+    check(O, rec, "adcensus_disp_left", dl)
+    check(O, rec, "adcensus_disp_right", dr)
+
+    agg = {}
+    disp = {}
+    for view, img, vol in (("left", L, adc.GetPtrLeft()), ("right", R, adc.GetPtrRight())):
+        ca = smt.CrossArmAggregation().Initialize(H, W, rec["tau"], D, DEV)
+        ca.ComputeArmLengths(T(img))
+        for nm, a in zip(("left", "right", "top", "bottom"), ca.arm_maps()):
+            check(O, rec, f"arms_{view}img_{nm}", a)
+        agg[view] = torch.empty((H, W, D), device=DEV)
+        disp[view] = torch.empty((H, W), device=DEV)
+        ca.AggregationVertical(vol, agg[view], disp[view])
+        ca.status()
+        check(O, rec, f"agg_vol_{view}", agg[view])
+        check(O, rec, f"agg_disp_{view}", disp[view])
+        ca.close()
+    del agg["right"]
+    adc.close()
+
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, rec["p1"], rec["p2"], DEV)
+    for which in ("left", "right", "up", "down"):
+        pv = so.ScanPass(agg["left"], Lf, which)
+        check(O, rec, "scan_path_" + which, pv)
+        del pv
+    out = torch.empty((H, W, D), device=DEV)
+    dso = torch.empty((H, W), device=DEV)
+    so.ScanLine(agg["left"], Lf, out, dso)
+    check(O, rec, "scan_sum", out)
+    check(O, rec, "scan_disp", dso)
+    so.close()
+
+    cls, nocc, nmis = smt.LeftRightConsistency(W, H, rec["gate"], dso, disp["right"])
+    check(O, rec, "lr_disp", dso)
+    check(O, rec, "lr_cls", cls)
+    assert (nocc, nmis) == (rec["lr_n_occlusion"], rec["lr_n_mismatch"])
+
+
+def test_config5_batch_hashes(smt, O, gold):
+    """configs[4]: the whole 256-pair KITTI-size batch through smt_adcensus_compute_batch; every pair's
+    two WTA maps against the oracle's, plus the last pair's volumes (the handle keeps only those)."""
+    from stereo_match_traditional_amd import synth
+    rec = gold["cfg5_kitti_d256_batch"]
+    H, W, D = rec["H"], rec["W"], rec["D"]
+    P = len(rec["pairs"])
+    assert P >= 1
+    Ls, Rs = zip(*[synth.synth_pair(H, W, D, rec["seed0"] + b) for b in range(P)])
+    Lb = T(np.stack(Ls).astype(np.float32))
+    Rb = T(np.stack(Rs).astype(np.float32))
+    dl = torch.empty((P, H, W), device=DEV)
+    dr = torch.empty((P, H, W), device=DEV)
+    adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, rec["sigmaC"], rec["sigmaS"])
+    adc.ComputeBatch(Lb, Rb, dl, dr)
+    adc.status()
+    dlh, drh = dl.cpu().numpy(), dr.cpu().numpy()
+    for b in range(P):
+        r = rec["pairs"][str(b)]
+        assert hx(O, dlh[b]) == r["adcensus_disp_left"], b
+        assert hx(O, drh[b]) == r["adcensus_disp_right"], b
+    last = rec["pairs"][str(P - 1)]
+    check(O, last, "adcensus_vol_left", adc.GetPtrLeft())
+    check(O, last, "adcensus_vol_right", adc.GetPtrRight())
+    adc.close()
