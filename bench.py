@@ -2,14 +2,20 @@
 """Headline benchmark: AD-Census (both views' [H,W,D] cost volumes + WTA) at 1920x1080, D=192.
 
 python bench.py --gpus N --steps K --warmup W
-One process per GPU (torch.distributed over RCCL when N > 1); pairs are independent, so
-each rank runs its own pairs with no data-path collective (weak scaling); one tiny
-all_gather of the last disparity map + a checksum all_reduce stand for config 5's gather.
-Prints ONE JSON line on rank 0.
+One process per GPU (torch.distributed over RCCL when N > 1); pairs are independent, so each rank runs
+its own pairs with no data-path collective (weak scaling); config 5's only exchange -- one all_gather of
+the disparity maps + a checksum all_reduce (shard.py) -- sits at the end of the timed region unless
+--no-gather is given, and is also timed by itself (extra.gather_ms).
+Prints ONE JSON line on rank 0.  After the timed region rank 0 also measures, outside `value`:
+  roofline.sclk_mhz / store_ceiling_ms   in-kernel shader clock of the cost kernel and the same-run
+                                         store-only ceiling of its store pattern (smt_adcensus_diag);
+  extra.configs                          BASELINE.json configs 1-5 with per-stage HIP-event times;
+  cpu_baseline                           the CPU oracle on a band of the same pair.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,13 +25,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_VECTOR_TFLOPS = 78.6   # dense fp64 vector peak
+F32_ADDS_PER_S = 78.6e12   # fp32 vector peak 157.3 TFLOP/s counts an FMA as 2: plain adds issue at half of it
 
 WORKLOADS = {
-    # name: (H, W, D, seed)
-    "adcensus_1080p_d192": (1080, 1920, 192, 3),   # BASELINE.json metric / configs[2] size
-    "adcensus_720p_d128": (720, 1280, 128, 2),     # configs[1]
-    "adcensus_kitti_d256": (375, 1242, 256, 1000), # configs[4] pair size
+    # name: (H, W, D, seed, description)
+    "adcensus_1080p_d192": (1080, 1920, 192, 3, "AD-Census 1920x1080 D=192"),   # BASELINE.json metric
+    "adcensus_720p_d128": (720, 1280, 128, 2, "AD-Census 1280x720 D=128"),      # configs[1]
+    "adcensus_kitti_d256": (375, 1242, 256, 1000, "AD-Census 1242x375 D=256"),  # configs[4] pair size
 }
 
 
@@ -35,6 +43,7 @@ def cpu_baseline(H, W, D, seed, rows=256):
     from oracle import oracle as orc
     from stereo_match_traditional_amd import synth
     L, R = synth.synth_pair(H, W, D, seed)
+    rows = min(rows, H)
     i0 = (H - rows) // 2
     i1 = i0 + rows
     t0 = time.perf_counter()
@@ -85,22 +94,157 @@ def pmc_traffic(workload):
         return None, None
 
 
+def smi_snapshot():
+    """Best-effort rocm-smi readings (child process; never fatal): temperatures, clocks, power."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower", "--json"], capture_output=True,
+                           text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(s in kl for s in ("temperature", "clock", "power")):
+                keep[k] = v
+        return keep
+    except Exception:
+        return None
+
+
+def ev_timed(fn, reps, warm=1):
+    """Mean milliseconds of fn() by HIP events on torch's current stream -- the stream api.py hands to
+    every smt_* call, i.e. the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def extra_configs(dev, reps=5):
+    """BASELINE.json configs 1-5 on this GPU, measured AFTER the headline's timed region (they are not
+    part of `value`).  Times are HIP-event means; fractions are algorithmic bytes or flops
+    over the spec peaks."""
+    import stereo_match_traditional_amd as smt
+    from stereo_match_traditional_amd import synth
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = {}
+
+    # ---- config 1: SAD 5x5, 450x375, D=64 (left view) -------------------------------------------
+    H, W, D = 375, 450, 64
+    L, R = synth.synth_pair(H, W, D, 1)
+    Lp, Rp = T(np.pad(L, 2, mode="edge")), T(np.pad(R, 2, mode="edge"))
+    ms = ev_timed(lambda: smt.GetPointDepthLeft(Lp, Rp, D, 1), 20)
+    out["cfg1_sad5x5_450x375_d64"] = {"ms_per_view": round(ms, 4), "Mdisp_s": round(H * W * D / ms / 1e3, 1),
+                                      "bound": "valu-int (volume never stored)"}
+
+    # ---- configs 2 and 5: AD-Census both views + WTA ---------------------------------------------
+    for key, (H, W, D, seed, P) in {"cfg2_adcensus_720p_d128": (720, 1280, 128, 2, 8),
+                                    "cfg5_adcensus_kitti_d256_batch": (375, 1242, 256, 1000, 16)}.items():
+        Ls, Rs = zip(*[synth.synth_pair(H, W, D, seed + b) for b in range(P)])
+        Lb, Rb = T(np.stack(Ls).astype(np.float32)), T(np.stack(Rs).astype(np.float32))
+        dl, dr = torch.empty((P, H, W), device=dev), torch.empty((P, H, W), device=dev)
+        adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, 10.0, 30.0)
+        single = ev_timed(lambda: adc.ComputeBoth(dl[0], dr[0]), 40, warm=5)
+        adc.timing(1)
+        batch = ev_timed(lambda: adc.ComputeBatch(Lb, Rb, dl, dr), 10, warm=2) / P
+        _, cost = adc.kernel_times()
+        adc.timing(False)
+        mhz, _, store_ms = adc.diag(20)
+        adc.status()
+        adc.close()
+        V = H * W * D
+        k_ms = float(np.mean(cost))
+        out[key] = {"ms_per_pair_single": round(single, 4), "ms_per_pair_batched": round(batch, 4), "batch": P,
+                    "Mdisp_s_batched": round(V / batch / 1e3, 1), "cost_kernel_ms": round(k_ms, 4),
+                    "alg_bytes_per_pair": 8 * V, "frac_hbm_peak": round(8 * V / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "store_ceiling_ms": round(store_ms, 4), "sclk_mhz": round(mhz, 1)}
+        del Lb, Rb, dl, dr
+
+    # ---- config 3: the north-star pipeline, main.cpp:59-92 order ----------------------------------
+    H, W, D = 1080, 1920, 192
+    V = H * W * D
+    L, R = synth.synth_pair(H, W, D, 3)
+    Lf, Rf, Lu, Ru = T(L.astype(np.float32)), T(R.astype(np.float32)), T(L), T(R)
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+    dL, dR = torch.empty((H, W), device=dev), torch.empty((H, W), device=dev)
+    st = {}
+    st["adcensus"] = ev_timed(lambda: adc.ComputeBoth(dL, dR), reps)
+    caL = smt.CrossArmAggregation().Initialize(H, W, 30, D, dev)
+    caR = smt.CrossArmAggregation().Initialize(H, W, 30, D, dev)
+    st["arms"] = ev_timed(lambda: (caL.ComputeArmLengths(Lu), caR.ComputeArmLengths(Ru)), reps)
+    area = {}
+    for nm, ca in (("left", caL), ("right", caR)):
+        a = [m.double() for m in ca.arm_maps()]
+        area[nm] = float(((a[0] + a[1] + 1) * (a[2] + a[3] + 1)).mean())
+    aggL, aggR = torch.empty((H, W, D), device=dev), torch.empty((H, W, D), device=dev)
+    st["aggregate_left"] = ev_timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL, dL), reps)
+    st["aggregate_right"] = ev_timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), reps)
+    caL.status()
+    caR.status()
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, dev)
+    sout = torch.empty((H, W, D), device=dev)
+    st["scanline"] = ev_timed(lambda: so.ScanLine(aggL, Lf, sout, dL), reps)
+    dLc = dL.clone()
+    st["lrcheck"] = ev_timed(lambda: (dLc.copy_(dL), smt.LeftRightConsistency(W, H, 2, dLc, dR)), reps)
+    total = sum(st.values())
+    alg = {"adcensus": 8, "aggregate_left": 8, "aggregate_right": 8, "scanline": 44}
+    stages = {}
+    for k, ms in st.items():
+        rec = {"ms": round(ms, 4)}
+        if k in alg:
+            rec["alg_bytes_per_hyp"] = alg[k]
+            rec["frac_hbm_peak"] = round(alg[k] * V / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if k.startswith("aggregate"):
+            # second roofline of the stage: the reference's add order is part of the contract, so the
+            # in-order fp32 adds cannot be shared between pixels: sum(area) * D adds per view
+            adds = area[k.split("_")[1]] * V
+            rec["mean_rect_area"] = round(area[k.split("_")[1]], 2)
+            rec["inorder_adds"] = adds
+            rec["frac_f32_add_peak"] = round(adds / (ms * 1e-3) / F32_ADDS_PER_S, 4)
+        stages[k] = rec
+    out["cfg3_pipeline_1080p_d192"] = {
+        "ms_per_pair": round(total, 4), "Mdisp_s": round(V / total / 1e3, 1), "alg_bytes_per_hyp": 68,
+        "frac_hbm_peak": round(68 * V / (total * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "stages": stages}
+    for o in (adc, caL, caR, so):
+        o.close()
+    del aggL, aggR, sout
+
+    # ---- config 4: ASW 35x35 (winSize 16), 960x540, D=128, left view ------------------------------
+    H, W, D, ws = 540, 960, 128, 16
+    L, R = synth.synth_pair(H, W, D, 4)
+    Lp, Rp = T(np.pad(L, ws + 1, mode="edge")), T(np.pad(R, ws + 1, mode="edge"))
+    sp, cm = smt.asw_masks(ws, 50.0, 30.0, dev)
+    ms = ev_timed(lambda: smt.AdaptiveSupportWeight(Lp, Rp, ws, D, sp, cm, 40), 2)
+    flops = 8.0 * 35 * 35 * H * W * D
+    out["cfg4_asw35x35_960x540_d128"] = {"ms_per_view": round(ms, 3), "Mdisp_s": round(H * W * D / ms / 1e3, 1),
+                                         "alg_flops_per_view": flops, "TFLOP_s_f64": round(flops / ms / 1e9, 2),
+                                         "frac_f64_vector_peak": round(flops / ms / 1e9 / F64_VECTOR_TFLOPS, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="adcensus_1080p_d192", choices=sorted(WORKLOADS))
-    ap.add_argument("--pairs-per-step", type=int, default=1)
+    ap.add_argument("--pairs-per-step", type=int, default=1, help="pairs per step PER GPU (config 5: 256/N)")
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the disparity gather out of the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra.configs (configs 1-5 after the timed region)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -109,11 +253,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)                   # RCCL on ROCm
 
     import stereo_match_traditional_amd as smt
-    from stereo_match_traditional_amd import synth
+    from stereo_match_traditional_amd import shard, synth
     from stereo_match_traditional_amd._lib import lib
     lib()  # no fallback: fail here if the HIP library is missing
 
-    H, W, D, seed = WORKLOADS[args.workload]
+    H, W, D, seed, desc = WORKLOADS[args.workload]
     P = args.pairs_per_step
     Ls, Rs = zip(*[synth.synth_pair(H, W, D, seed + 7919 * rank + b) for b in range(P)])
     Lb = torch.from_numpy(np.stack(Ls).astype(np.float32)).to(dev)
@@ -121,6 +265,7 @@ def main():
     dl = torch.empty((P, H, W), device=dev)
     dr = torch.empty((P, H, W), device=dev)
     adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, 10.0, 30.0)
+    smi_before = smi_snapshot() if rank == 0 else None
 
     def step():
         adc.ComputeBatch(Lb, Rb, dl, dr)
@@ -140,21 +285,32 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if dist.is_initialized():
-        # config 5's only exchange: gather the disparity maps, all-reduce a checksum (shard.py)
-        from stereo_match_traditional_amd import shard
+    gather_ms = None
+    if dist.is_initialized() and not args.no_gather:
+        # config 5's only exchange: gather the disparity maps, all-reduce a checksum (shard.py).  The
+        # synchronize in front only separates the two clocks; the barrier below would wait for it anyway.
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         shard.gather_disparities(dl, world * P)
         shard.checksum(dl)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     prep_ms, cost_ms = adc.kernel_times()
     adc.timing(False)
     adc.status()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, gather_ms or 0.0], dtype=torch.float64, device=dev)
     if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, gather_ms = float(tt[0].item()), (float(tt[1].item()) if gather_ms is not None else None)
+
+    # same-run diagnostics of the dominant kernel, right after the timed region (same DVFS / memory state)
+    diag = None
+    if rank == 0 and D % 64 == 0:
+        mhz, stamped_ms, store_ms = adc.diag(20)
+        diag = (mhz, stamped_ms, store_ms)
 
     if rank == 0:
         hyp_pair = H * W * D
@@ -165,8 +321,29 @@ def main():
         k_ms = float(np.mean(cost_ms)) if cost_ms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "k_cost_fast2 (cost volume + fused WTA, both views)",
+                "kernel_ms": round(k_ms, 4), "tables_ms": round(float(np.mean(prep_ms)), 4),
+                "timed_launches": len(cost_ms), "timed_every": stride,
+                "algorithmic_bytes_per_launch": alg_bytes}
+        if diag:
+            mhz, stamped_ms, store_ms = diag
+            roof.update({"sclk_mhz": round(mhz, 1), "store_ceiling_ms": round(store_ms, 4),
+                         "store_ceiling_GBs": round(alg_bytes / (store_ms * 1e-3) / 1e9, 1),
+                         "frac_of_store_ceiling": round(store_ms / k_ms, 4),
+                         "stamped_kernel_ms": round(stamped_ms, 4),
+                         "diag": "smt_adcensus_diag right after the timed region: store-only twin of the kernel "
+                                 "(same grid, chunk order, streaming stores, same buffers) and the kernel with "
+                                 "s_memtime/s_memrealtime stamps, 20 launches each"})
+        tries, place_ms = adc.placement()
+        roof["placement"] = {"candidate_pairs_tried": tries, "kept_pair_store_only_ms": round(place_ms, 4),
+                             "note": "smt_adcensus_create keeps the fastest of up to 6 allocations of the two volumes "
+                                     "(HBM write rate depends on the physical pages, DESIGN.md section 5)"}
+        roof["smi_before"] = smi_before
+        roof["smi_after"] = smi_snapshot()
         out = {
-            "metric": "Mdisparities/s (HxWxD/s) + ms/pair, AD-Census 1920x1080 D=192",
+            "metric": f"Mdisparities/s (HxWxD/s) + ms/pair, {desc}",
             "value": round(value, 2),
             "unit": "Mdisp/s",
             "n_gpus": world,
@@ -180,18 +357,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"AD-Census 9x7 both views + WTA, {W}x{H} D={D} ({args.workload})",
-                       "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_cost (cost volume + fused WTA, both views)",
-                         "kernel_ms": round(k_ms, 4), "tables_ms": round(float(np.mean(prep_ms)), 4),
-                         "timed_launches": len(cost_ms), "timed_every": stride,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                       "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)",
+                       "gather_in_timed_region": bool(dist.is_initialized() and not args.no_gather)},
+            "roofline": roof,
         }
+        extra = {}
+        if gather_ms is not None:
+            extra["gather_ms"] = round(gather_ms, 3)
+            extra["value_without_gather"] = round(total_pairs * hyp_pair / (dt - gather_ms * 1e-3) / 1e6, 2)
+        if world == 1 and not args.no_extras:
+            try:
+                extra["configs"] = extra_configs(dev)
+            except Exception as e:                       # never lose the headline line to an extra
+                extra["configs_error"] = repr(e)
+        if extra:
+            out["extra"] = extra
         if world == 1 and args.cpu_rows > 0:
             out["cpu_baseline"] = cpu_baseline(H, W, D, seed, args.cpu_rows)
         print(json.dumps(out), flush=True)
+    adc.close()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

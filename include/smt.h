@@ -59,6 +59,18 @@ int smt_version(void);
 int smt_last_hip_error(void);
 int smt_device_count(int *count);
 int smt_set_device(int device);
+/* Devices.  A handle lives on the HIP device that was current in the calling thread when it was created
+ * (smt_*_create) or on the one named explicitly (smt_*_create_on(device, ...), same arguments otherwise);
+ * its entry points make that device current for the duration of the call and restore the caller's, so
+ * one host thread can drive a handle per GPU.  Buffers and streams passed to a handle must belong to its
+ * device.  The stateless entry points (smt_wta, smt_lrcheck, smt_sad, ...) run on the device that is
+ * current in the calling thread.
+ *
+ * Limits (the reference has none; outside them SMT_ERR_ARG):  dispRange D <= 256 on every entry point
+ * (one wavefront spans the disparity axis, at most 4 hypotheses per lane); ASW window side
+ * 2*(winSize+1)+1 <= 64 (winSize <= 30; one window row per wavefront pass); MedianFilter wnd_size <= 7;
+ * volumes of 4 GiB or more take the plain one-pixel-per-wave aggregation kernel (32-bit tap offsets in
+ * the shared-tap kernels). */
 
 /* ---- device memory helpers (plumbing; not part of the reference's surface) ---------- */
 int smt_malloc(void **dptr, size_t bytes);
@@ -105,7 +117,14 @@ int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms
  * costVolumeRight) plus census tables.  The reference's separate AD / census volumes
  * (ADcostVolum, CensusVolum, ...) are never materialised. */
 int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out);
+int smt_adcensus_create_on(int device, int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out);
 int smt_adcensus_destroy(smt_adcensus *h);
+/* How smt_adcensus_create placed the two volumes: it allocates up to 6 candidate pairs, times a
+ * store-only twin of the cost kernel on each and keeps the fastest (the HBM write rate of the same
+ * kernel differs by ~18 % between allocations); SMT_PLACEMENT=0 in the
+ * environment disables the search.  tries = candidate pairs allocated, store_only_ms = the kept pair's
+ * store-only time (0 when there was no search).  Either pointer may be NULL. */
+int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_only_ms);
 int smt_adcensus_set_stream(smt_adcensus *h, void *stream);
 
 /* ComputeADcensus (AD-Census.h:271-294) for SMT_VIEW_LEFT, ComputeADcensusRight
@@ -172,6 +191,7 @@ void smt_crossarm_cblsm_params(smt_crossarm_params *p);   /* CBLSM.cpp values */
 /* CrossArmAggregation::Initialize (CrossArm.cpp:6-18): allocates the four arm maps and
  * resets the sticky threshold. */
 int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out);
+int smt_crossarm_create_on(int device, int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out);
 int smt_crossarm_destroy(smt_crossarm *h);
 int smt_crossarm_set_stream(smt_crossarm *h, void *stream);
 
@@ -223,6 +243,9 @@ int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps (all variants but 1;
  * variants 3 and 4 round it to 8, 16 or a multiple of 32). */
 int smt_crossarm_set_strip_width(smt_crossarm *h, int width);
+/* Tuning hook (variants 3-5): 0 = column strips interleaved over the 8 XCDs, 1 = every XCD owns one
+ * contiguous band of rows and sweeps it strip by strip.  Placement only; results are identical. */
+int smt_crossarm_set_sweep(smt_crossarm *h, int sweep);
 
 /* CBLSM.h:327-381 ComputeAD / ComputeADRight on uchar images -> float volume. */
 int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int view, float *vol,
@@ -248,6 +271,7 @@ typedef struct smt_scanline smt_scanline;
 /* ScanlineOptimizer::Initialize (:66-79).  The reference allocates five volumes; this
  * engine keeps one scratch volume. */
 int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanline **out);
+int smt_scanline_create_on(int device, int H, int W, int D, int p1, int p2, smt_scanline **out);
 int smt_scanline_destroy(smt_scanline *h);
 int smt_scanline_set_stream(smt_scanline *h, void *stream);
 
@@ -314,6 +338,7 @@ typedef struct smt_crossagg smt_crossagg;
 /* Initialize(width,height,min_disparity,max_disparity) (:19-58). D = max-min.
  * Returns SMT_ERR_ARG where the reference returns false. */
 int smt_crossagg_create(int W, int H, int D, smt_crossagg **out);
+int smt_crossagg_create_on(int device, int W, int H, int D, smt_crossagg **out);
 int smt_crossagg_destroy(smt_crossagg *h);
 int smt_crossagg_set_stream(smt_crossagg *h, void *stream);
 /* SetParams (:67-74); defaults L1=34 L2=17 t1=20 t2=6 (adcensus_types.h:69-70). */

@@ -150,6 +150,12 @@ class AD_Census:
         check(lib().smt_adcensus_kernel_times(self._h, a, b, cap, C.byref(n)), "smt_adcensus_kernel_times")
         return list(a[:n.value]), list(b[:n.value])
 
+    def placement(self):
+        """(candidate volume pairs tried at Initialize, store-only ms of the pair kept)."""
+        n, ms = C.c_int(), C.c_float()
+        check(lib().smt_adcensus_placement(self._h, C.byref(n), C.byref(ms)), "smt_adcensus_placement")
+        return n.value, ms.value
+
     def diag(self, reps=20):
         """smt_adcensus_diag: (in-kernel shader clock in MHz, stamped cost-kernel ms, store-only ms)."""
         self._bind_stream()
@@ -292,6 +298,9 @@ class CrossArmAggregation:
         """4 = 2x8 pixels per wave sharing union taps (default), 5 = same without group skip, 3 = 1x8,
         0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
+
+    def set_sweep(self, sweep):
+        check(lib().smt_crossarm_set_sweep(self._h, int(sweep)), "smt_crossarm_set_sweep")
 
     def set_strip_width(self, w):
         check(lib().smt_crossarm_set_strip_width(self._h, int(w)), "smt_crossarm_set_strip_width")

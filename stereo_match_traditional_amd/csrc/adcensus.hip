@@ -24,6 +24,7 @@
 // LDS once per workgroup; WTA is a wave min + ballot (first strict minimum, :355-373).
 #include "smt_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <new>
 #include <type_traits>
@@ -626,6 +627,7 @@ __global__ void __launch_bounds__(NT) k_wta(const float *__restrict__ vol, int N
 thread_local int g_smt_last_hip = 0;
 
 struct smt_adcensus {
+    int device;          // HIP device the handle lives on
     int H, W, D;
     float sigmaC, sigmaS;
     hipStream_t stream;
@@ -642,6 +644,8 @@ struct smt_adcensus {
     long n_seen;         // pairs processed since timing was (re-)enabled
     int timing_stride;   // every timing_stride-th pair is recorded
     bool *ev_merged;     // slot recorded 3 events (tables end == cost start, one stream)
+    int place_tries;     // candidate volume pairs tried by place_volumes
+    float place_ms;      // store-only time of the pair that was kept (0: no search)
 };
 
 SMT_API const char *smt_strerror(int s)
@@ -700,20 +704,95 @@ SMT_API int smt_stream_create(void **s)
 SMT_API int smt_stream_destroy(void *s) { SMT_HIP(hipStreamDestroy(smt_stream(s))); return SMT_OK; }
 SMT_API int smt_stream_sync(void *s) { SMT_HIP(hipStreamSynchronize(smt_stream(s))); return SMT_OK; }
 
+template <int C>
+static void launch_store_only(smt_adcensus *h, float *v0, float *v1, hipStream_t st)
+{
+    const int nbx = (h->W + FTJ - 1) / FTJ;
+    const unsigned nblk = (unsigned)(((long)nbx * h->H * 2 + 7) / 8 * 8);
+    hipLaunchKernelGGL((k_store_only2<C>), dim3(nblk), dim3(NT), 0, st, h->H, h->W, v0, v1, nbx);
+}
+static void store_only(smt_adcensus *h, float *v0, float *v1, hipStream_t st)
+{
+    switch (h->D / 64) {
+    case 1: launch_store_only<1>(h, v0, v1, st); break;
+    case 2: launch_store_only<2>(h, v0, v1, st); break;
+    case 3: launch_store_only<3>(h, v0, v1, st); break;
+    default: launch_store_only<4>(h, v0, v1, st); break;
+    }
+}
+
+// Placement-aware allocation of the two cost volumes.  The cost kernel is a pure store stream (8 XCDs,
+// each writing its own contiguous eighth of the two volumes), and what that stream reaches depends on
+// WHICH physical pages hipMalloc handed out: on one MI355X, in one process, at a constant 2.37 GHz shader
+// clock, the store-only twin of the kernel runs at either ~7.0 TB/s or ~5.9 TB/s on successive
+// allocations of the same size, and the same virtual range re-allocated later lands in the other mode
+// (tools/alloc_probe.hip).  Nothing in the kernel can change that afterwards, so
+// Initialize takes up to PLACE_TRIES candidate pairs, times the store-only twin on each (a few launches,
+// ~5 ms per candidate at 1080p x 192), keeps the fastest and frees the rest.  Rejected candidates stay
+// allocated until the end so that every try gets different pages.  SMT_PLACEMENT=0 in the environment
+// turns the search off (first allocation is used).
+static int place_volumes(smt_adcensus *h)
+{
+    const size_t V = (size_t)h->H * h->W * h->D;
+    constexpr int PLACE_TRIES = 6;
+    const char *env = getenv("SMT_PLACEMENT");
+    const bool search = !(env && env[0] == '0') && h->D % 64 == 0 && h->D <= 256 && V >= ((size_t)1 << 22);
+    float *cand[PLACE_TRIES][2] = {};
+    float ms[PLACE_TRIES];
+    int n = 0, best = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (search && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return SMT_ERR_HIP;
+    // a candidate at this rate is in the fast mode (7.0 TB/s measured at 1080p x 192): stop looking
+    const double good_ms = 2.0 * V * 4 / 6.75e12 * 1e3;
+    for (; n < (search ? PLACE_TRIES : 1); n++) {
+        if (smt_malloc((void **)&cand[n][0], V * 4) != SMT_OK) break;
+        if (smt_malloc((void **)&cand[n][1], V * 4) != SMT_OK) { (void)hipFree(cand[n][0]); cand[n][0] = nullptr; break; }
+        if (!search) { best = n; n++; break; }
+        const int reps = 8;
+        for (int k = 0; k < 3; k++) store_only(h, cand[n][0], cand[n][1], nullptr);
+        (void)hipEventRecord(e0, nullptr);
+        for (int k = 0; k < reps; k++) store_only(h, cand[n][0], cand[n][1], nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        float t = 0;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) t = 1e30f;
+        ms[n] = t / reps;
+        if (best < 0 || ms[n] < ms[best]) best = n;
+        if (ms[n] <= good_ms) { n++; break; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (int k = 0; k < n; k++)
+        if (k != best) { (void)hipFree(cand[k][0]); (void)hipFree(cand[k][1]); }
+    if (best < 0) return SMT_ERR_ALLOC;
+    h->vol[0] = cand[best][0]; h->vol[1] = cand[best][1];
+    h->place_tries = n;
+    h->place_ms = search ? ms[best] : 0.0f;
+    return SMT_OK;
+}
+
+SMT_API int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_only_ms)
+{
+    if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
+    if (tries) *tries = h->place_tries;
+    if (store_only_ms) *store_only_ms = h->place_ms;
+    return SMT_OK;
+}
+
 SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
 {
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256 || !(sigmaC > 0.0f) || !(sigmaS > 0.0f))
         return SMT_ERR_ARG;
     smt_adcensus *h = new (std::nothrow) smt_adcensus();
     if (!h) return SMT_ERR_ALLOC;
+    h->device = smt_current_device();
     h->H = H; h->W = W; h->D = D; h->sigmaC = sigmaC; h->sigmaS = sigmaS;
     h->stream = nullptr; h->timing = false; h->force_generic = false; h->ev = nullptr; h->n_timed = 0; h->n_seen = 0; h->timing_stride = 1; h->ev_merged = nullptr;
     h->n_pairs = 0;
     const size_t N = (size_t)H * W, V = N * D;
     const int WX = W + 4;
-    int rc = SMT_OK;
+    int rc = place_volumes(h);
     auto alloc = [&](void **p, size_t bytes) { if (rc == SMT_OK) rc = smt_malloc(p, bytes); };
-    alloc((void **)&h->vol[0], V * 4); alloc((void **)&h->vol[1], V * 4);
     alloc((void **)&h->TS[0].lut, 320 * 4);
     alloc((void **)&h->TS[0].flag, 4);
     for (int t = 0; t < 2; t++) {
@@ -757,9 +836,18 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     return SMT_OK;
 }
 
+SMT_API int smt_adcensus_create_on(int device, int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(device);
+    return smt_adcensus_create(H, W, D, sigmaC, sigmaS, out);
+}
+
 SMT_API int smt_adcensus_destroy(smt_adcensus *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (h->prep_stream) { (void)hipStreamSynchronize(h->prep_stream); (void)hipStreamDestroy(h->prep_stream); }
     if (h->in_ready) (void)hipEventDestroy(h->in_ready);
     for (int t = 0; t < 2; t++) {
@@ -786,6 +874,7 @@ SMT_API int smt_adcensus_destroy(smt_adcensus *h)
 SMT_API int smt_adcensus_set_stream(smt_adcensus *h, void *s)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->stream = smt_stream(s);
     return SMT_OK;
 }
@@ -889,6 +978,7 @@ SMT_API int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R
                                  float *dispL, float *dispR)
 {
     if (!h || !L || !R || views < 1 || views > 3) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     return adcensus_pair(h, L, R, views, dispL, dispR, false);
 }
 
@@ -898,6 +988,7 @@ SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const fl
                                        int views, float *dispL, float *dispR)
 {
     if (!h || !L || !R || pairs <= 0 || views < 1 || views > 3) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     const size_t N = (size_t)h->H * h->W;
     const bool ov = pairs > 1 && overlap_pays(h);
     if (ov) {
@@ -916,6 +1007,7 @@ SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const fl
 SMT_API int smt_adcensus_volume(smt_adcensus *h, int view, float **vol)
 {
     if (!h || !vol || (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT)) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     *vol = h->vol[view == SMT_VIEW_LEFT ? 0 : 1];
     return SMT_OK;
 }
@@ -923,6 +1015,7 @@ SMT_API int smt_adcensus_volume(smt_adcensus *h, int view, float **vol)
 SMT_API int smt_adcensus_status(smt_adcensus *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     int f = 0;
     SMT_HIP(hipMemcpyAsync(&f, h->T.flag, 4, hipMemcpyDeviceToHost, h->stream));
     SMT_HIP(hipMemsetAsync(h->T.flag, 0, 4, h->stream));            // read-and-clear
@@ -933,6 +1026,7 @@ SMT_API int smt_adcensus_status(smt_adcensus *h)
 SMT_API int smt_adcensus_force_generic(smt_adcensus *h, int on)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->force_generic = on != 0;
     return SMT_OK;
 }
@@ -940,6 +1034,7 @@ SMT_API int smt_adcensus_force_generic(smt_adcensus *h, int on)
 SMT_API int smt_adcensus_timing(smt_adcensus *h, int enable)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (enable && !h->ev) {
         h->ev = new (std::nothrow) hipEvent_t[SMT_TIMING_SLOTS * 4];
         h->ev_merged = new (std::nothrow) bool[SMT_TIMING_SLOTS]();
@@ -958,6 +1053,7 @@ SMT_API int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *co
                                       int *count)
 {
     if (!h || !count || capacity < 0) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (!h->ev) return SMT_ERR_STATE;
     long n = h->n_timed < SMT_TIMING_SLOTS ? h->n_timed : SMT_TIMING_SLOTS;
     if (n > capacity) n = capacity;
@@ -981,6 +1077,7 @@ SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float 
                               float *store_only_ms)
 {
     if (!h || reps <= 0 || reps > 1000) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (h->n_pairs == 0) return SMT_ERR_STATE;               // needs the tables of a computed pair
     const int D = h->D, C = D / 64;
     if (D % 64 != 0 || C < 1 || C > 4) return SMT_ERR_ARG;

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(NT) k_ca_pass(const float *__restrict__ src, f
 }  // namespace
 
 struct smt_crossagg {
+    int device;
     int W, H, D;
     int L1, L2, t1, t2;
     hipStream_t stream;
@@ -125,6 +126,7 @@ SMT_API int smt_crossagg_create(int W, int H, int D, smt_crossagg **out)
     if ((long)W * H <= 0 || W <= 0 || H <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;   // Initialize returns false (:28-31)
     smt_crossagg *h = new (std::nothrow) smt_crossagg();
     if (!h) return SMT_ERR_ALLOC;
+    h->device = smt_current_device();
     h->W = W; h->H = H; h->D = D;
     h->L1 = 34; h->L2 = 17; h->t1 = 20; h->t2 = 6;                       // adcensus_types.h:69-70
     const size_t N = (size_t)W * H;
@@ -138,9 +140,18 @@ SMT_API int smt_crossagg_create(int W, int H, int D, smt_crossagg **out)
     return SMT_OK;
 }
 
+SMT_API int smt_crossagg_create_on(int device, int W, int H, int D, smt_crossagg **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(device);
+    return smt_crossagg_create(W, H, D, out);
+}
+
 SMT_API int smt_crossagg_destroy(smt_crossagg *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     (void)hipFree(h->cur); (void)hipFree(h->tmp); (void)hipFree(h->arms);
     (void)hipFree(h->cnt[0]); (void)hipFree(h->cnt[1]);
     delete h;
@@ -150,6 +161,7 @@ SMT_API int smt_crossagg_destroy(smt_crossagg *h)
 SMT_API int smt_crossagg_set_stream(smt_crossagg *h, void *s)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->stream = smt_stream(s);
     return SMT_OK;
 }
@@ -157,6 +169,7 @@ SMT_API int smt_crossagg_set_stream(smt_crossagg *h, void *s)
 SMT_API int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int t2)
 {
     if (!h || L1 < 0) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->L1 = L1; h->L2 = L2; h->t1 = t1; h->t2 = t2;
     return SMT_OK;
 }
@@ -183,6 +196,7 @@ static void ca_iter(smt_crossagg *h, bool hfirst)
 SMT_API int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img, const float *cost_init, int iters)
 {
     if (!h || !img || !cost_init || iters < 0) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     const int N = h->W * h->H;
     hipLaunchKernelGGL(k_ca_arms, dim3((N + NT - 1) / NT), dim3(NT), 0, h->stream, img, h->W, h->H, h->L1, h->L2,
                        h->t1, h->t2, h->arms);                            // BuildArms :76-86
@@ -206,6 +220,7 @@ SMT_API int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img, const fl
 SMT_API int smt_crossagg_cost(smt_crossagg *h, float **cost)
 {
     if (!h || !cost) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     *cost = h->cur;
     return SMT_OK;
 }
@@ -213,6 +228,7 @@ SMT_API int smt_crossagg_cost(smt_crossagg *h, float **cost)
 SMT_API int smt_crossagg_arms(smt_crossagg *h, uint8_t **arms)
 {
     if (!h || !arms) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     *arms = h->arms;
     return SMT_OK;
 }

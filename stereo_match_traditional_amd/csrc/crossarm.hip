@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
-                                                        int *ub_flag, int SW, const float *__restrict__ member)
+                                                        int *ub_flag, int SW, const float *__restrict__ member, int sweep)
 {
     constexpr int QC = 8, NPIX = QC * QR;
     constexpr int G = (QR == 1) ? 8 : 4;                 // union taps loaded per group
@@ -558,11 +558,24 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
         const int wx = min(NT / 64, SW / QC), wy = (NT / 64) / wx;
         const int gpr = SW / (QC * wx);
         const int nband = (H + wy * QR - 1) / (wy * QR);
-        const int gps = gpr * nband;
-        const int strip = xcd + 8 * (slot / gps);
-        const int g = slot % gps;
-        const int row = ((g / gpr) * wy + wv / wx) * QR;
-        const int col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
+        int row, col;
+        if (sweep == 0) {
+            // strips interleaved over the XCDs: XCD x sweeps strips x, x+8, ... top to bottom
+            const int gps = gpr * nband;
+            const int strip = xcd + 8 * (slot / gps);
+            const int g = slot % gps;
+            row = ((g / gpr) * wy + wv / wx) * QR;
+            col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
+        } else {
+            // XCD x owns the x-th contiguous band of rows and sweeps it strip by strip: the column halo
+            // between neighbouring strips stays inside one XCD's L2 instead of being fetched by two
+            const int nbx = (nband + 7) >> 3;              // workgroup rows per XCD
+            const int gps = gpr * nbx;
+            const int strip = slot / gps;
+            const int g = slot % gps;
+            row = ((xcd * nbx + g / gpr) * wy + wv / wx) * QR;
+            col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
+        }
         if (row >= H || col >= W) return;
         p0 = row * W + col;
         ncol = min(QC, W - col);
@@ -650,6 +663,30 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
         }
     };
 
+    // SKIP == 2: the flag rows of a tap (QR x 8 floats, one s_load_dwordx8 per row of pixels) are fetched
+    // one tap AHEAD of the FMAs that use them, into the other half of a two-deep SGPR buffer, so the scalar
+    // cache latency hides behind the previous tap's FMAs instead of sitting in front of every live group
+    // (SKIP == 1 loads four flags per live group and waits for them on the spot).
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    auto load_flags = [&](unsigned m, f8 (&F)[QR]) {
+#pragma unroll
+        for (int h = 0; h < QR; h++) F[h] = *reinterpret_cast<const f8 *>(member + ((m >> (8 * h)) & 255u) * 8u);
+    };
+    auto fma_flagged = [&](unsigned m, const f8 (&F)[QR], const float (&x)[C]) {
+#pragma unroll
+        for (int h = 0; h < QR; h++) {
+            const unsigned mb = (m >> (8 * h)) & 255u;
+            auto pair = [&](int j) {
+                const f2 fl = f2{F[h][2 * j], F[h][2 * j + 1]};
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    acc[4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+            };
+            if (mb & 0x0fu) { pair(0); pair(1); }
+            if (mb & 0xf0u) { pair(2); pair(3); }
+        }
+    };
+
     if (!ub) {
         const int nIb = imax - imin + 1;
         const int total = (omax - omin + 1) * nIb;
@@ -699,8 +736,21 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
+                if (SKIP == 2) {
+                    f8 F[2][QR];
+                    load_flags(m[0], F[0]);
 #pragma unroll
-                for (int k = 0; k < GG; k++) add_flagged(m[k], x[k]);
+                    for (int k = 0; k < GG; k++) {
+                        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this tap's flags are in
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k + 1 < GG) load_flags(m[k + 1], F[(k + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fma_flagged(m[k], F[k & 1], x[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < GG; k++) add_flagged(m[k], x[k]);
+                }
             };
             int cnt = __builtin_popcountll(live);
             for (; cnt >= G; cnt -= G) group(std::integral_constant<int, G>{}, std::false_type{});
@@ -844,6 +894,7 @@ __global__ void __launch_bounds__(NT) k_choose_arm(int dir, const int *__restric
 }  // namespace
 
 struct smt_crossarm {
+    int device;
     int H, W, D;
     smt_crossarm_params P;
     hipStream_t stream;
@@ -853,6 +904,7 @@ struct smt_crossarm {
     int variant;         // aggregation kernel variant (test / tuning hook)
     int strip_w;         // column-strip width of the XCD-aware pixel order (variants 0 and 2)
     int strip_w8;        // the same for variant 3 (8 pixels per wave)
+    int sweep;           // 0: strips interleaved over XCDs, 1: each XCD owns a band of rows (variants 3-5)
     float *member;       // 256 x 8 membership flags for variant 3
 };
 
@@ -873,6 +925,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
+    h->device = smt_current_device();
     h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 16; h->variant = 4;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
@@ -896,9 +949,18 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     return SMT_OK;
 }
 
+SMT_API int smt_crossarm_create_on(int device, int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(device);
+    return smt_crossarm_create(H, W, D, p, out);
+}
+
 SMT_API int smt_crossarm_destroy(smt_crossarm *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     for (int k = 0; k < 4; k++) (void)hipFree(h->arm[k]);
     (void)hipFree(h->flip);
     (void)hipFree(h->member);
@@ -909,6 +971,7 @@ SMT_API int smt_crossarm_destroy(smt_crossarm *h)
 SMT_API int smt_crossarm_set_stream(smt_crossarm *h, void *s)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->stream = smt_stream(s);
     return SMT_OK;
 }
@@ -918,6 +981,7 @@ static const int kFlipInit[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
 SMT_API int smt_crossarm_reset(smt_crossarm *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     const size_t N = (size_t)h->H * h->W;
     // `new int[col*row]()` zero-initialises every map on each Initialize (CrossArm.cpp:14-17);
     // with the stride bug most of rightLength stays 0.
@@ -931,6 +995,7 @@ SMT_API int smt_crossarm_reset(smt_crossarm *h)
 SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
 {
     if (!h || !img || (channels != 1 && channels != 3)) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     const bool fix = (h->P.quirks & SMT_QUIRK_FIX_RIGHT_ARM_STRIDE) != 0;
     // with the stride bug the reference reads image columns up to H-1+max_length-ish of a
     // W-wide row: undefined for portrait images
@@ -955,6 +1020,7 @@ SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
 SMT_API int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channels, int dir)
 {
     if (!h || !img || (channels != 1 && channels != 3) || dir < 0 || dir > 3) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     const bool fix = (h->P.quirks & SMT_QUIRK_FIX_RIGHT_ARM_STRIDE) != 0;
     if (dir == 1 && !fix && h->H > h->W) return SMT_ERR_REF_UB;
     ArmCfg c{h->H, h->W, channels, h->P.tau, h->P.tau_low, h->P.sec_length, h->P.max_length,
@@ -975,6 +1041,7 @@ SMT_API int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channe
 SMT_API int smt_crossarm_tau(smt_crossarm *h, int *tau)
 {
     if (!h || !tau) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     SMT_HIP(hipMemcpyAsync(tau, h->flip + 5, 4, hipMemcpyDeviceToHost, h->stream));
     SMT_HIP(hipStreamSynchronize(h->stream));
     return SMT_OK;
@@ -983,6 +1050,7 @@ SMT_API int smt_crossarm_tau(smt_crossarm *h, int *tau)
 SMT_API int smt_crossarm_arm_maps(smt_crossarm *h, int **l, int **r, int **t, int **b)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (l) *l = h->arm[0];
     if (r) *r = h->arm[1];
     if (t) *t = h->arm[2];
@@ -1028,13 +1096,14 @@ static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, flo
     const int nstrips = (h->W + SW - 1) / SW;
     const int per_xcd = (nstrips + 7) / 8;
     const int nband = (h->H + wy * QR - 1) / (wy * QR);
-    dim3 grid((unsigned)(8 * per_xcd * (SW / (8 * wx)) * nband));
+    dim3 grid(h->sweep == 0 ? (unsigned)(8 * per_xcd * (SW / (8 * wx)) * nband)
+                            : (unsigned)(8 * nstrips * (SW / (8 * wx)) * ((nband + 7) / 8)));
     const int C = (h->D + 63) / 64;
     const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
 #define SMT_AGGM(CC, FF)                                                                                  \
     hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
-                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member)
+                       h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member, h->sweep)
     switch (C * 2 + (full ? 1 : 0)) {
     case 2: SMT_AGGM(1, false); break;
     case 3: SMT_AGGM(1, true); break;
@@ -1096,6 +1165,7 @@ static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *di
 SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vout, int order, float *disp)
 {
     if (!h || !vin || !vout || vin == vout || order < 0 || order > 2) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (!h->have_arms) return SMT_ERR_STATE;
     // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership
     // flags, groups of 4 pixels without a member skipped (default); 5 = the same without the skip;
@@ -1111,6 +1181,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 3) { if (order == 0) launch_agg_multi<0, 1, 0>(h, vin, vout, disp); else launch_agg_multi<1, 1, 0>(h, vin, vout, disp); }
     else if (variant == 4) { if (order == 0) launch_agg_multi<0, 2, 1>(h, vin, vout, disp); else launch_agg_multi<1, 2, 1>(h, vin, vout, disp); }
     else if (variant == 5) { if (order == 0) launch_agg_multi<0, 2, 0>(h, vin, vout, disp); else launch_agg_multi<1, 2, 0>(h, vin, vout, disp); }
+    else if (variant == 6) { if (order == 0) launch_agg_multi<0, 2, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 2>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1118,7 +1189,8 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 5) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 6) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->variant = variant;
     return SMT_OK;
 }
@@ -1126,13 +1198,23 @@ SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 SMT_API int smt_crossarm_set_strip_width(smt_crossarm *h, int w)
 {
     if (!h || w < 4 || (w & 3)) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->strip_w = w; h->strip_w8 = w;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_set_sweep(smt_crossarm *h, int sweep)
+{
+    if (!h || sweep < 0 || sweep > 1) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
+    h->sweep = sweep;
     return SMT_OK;
 }
 
 SMT_API int smt_crossarm_status(smt_crossarm *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     int f = 0;
     SMT_HIP(hipMemcpyAsync(&f, h->flip + 4, 4, hipMemcpyDeviceToHost, h->stream));
     SMT_HIP(hipMemsetAsync(h->flip + 4, 0, 4, h->stream));          // read-and-clear: reports what happened since the last call

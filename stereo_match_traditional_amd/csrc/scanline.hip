@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(NT) k_scan_lr(ScanArgs a)
 }  // namespace
 
 struct smt_scanline {
+    int device;
     int H, W, D, p1, p2;
     hipStream_t stream;
     float *scratch;      // one [H][W][D] volume: the right path until the up pass consumes it
@@ -259,13 +260,22 @@ SMT_API int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanlin
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
     smt_scanline *h = new (std::nothrow) smt_scanline();
     if (!h) return SMT_ERR_ALLOC;
+    h->device = smt_current_device();
     h->H = H; h->W = W; h->D = D; h->p1 = p1; h->p2 = p2; h->stream = nullptr; h->scratch = nullptr;
     *out = h;
     return SMT_OK;
 }
+SMT_API int smt_scanline_create_on(int device, int H, int W, int D, int p1, int p2, smt_scanline **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(device);
+    return smt_scanline_create(H, W, D, p1, p2, out);
+}
 SMT_API int smt_scanline_destroy(smt_scanline *h)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (h->scratch) (void)hipFree(h->scratch);
     delete h;
     return SMT_OK;
@@ -273,6 +283,7 @@ SMT_API int smt_scanline_destroy(smt_scanline *h)
 SMT_API int smt_scanline_set_stream(smt_scanline *h, void *s)
 {
     if (!h) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     h->stream = smt_stream(s);
     return SMT_OK;
 }
@@ -330,6 +341,7 @@ static int scan_pass(smt_scanline *h, const ScanArgs &a, int pass, int mode)
 SMT_API int smt_scanline_pass(smt_scanline *h, const float *vin, const float *gray, int pass, float *vout)
 {
     if (!h || !vin || !gray || !vout || vin == vout || pass < 0 || pass > 3) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     ScanArgs a{vin, gray, vout, nullptr, nullptr, nullptr, h->H, h->W, h->D, (float)h->p1, (float)h->p2};
     return scan_pass(h, a, pass, 0);
 }
@@ -337,6 +349,7 @@ SMT_API int smt_scanline_pass(smt_scanline *h, const float *vin, const float *gr
 SMT_API int smt_scanline_run(smt_scanline *h, const float *vin, const float *gray, float *vout, float *disp)
 {
     if (!h || !vin || !gray || !vout || vin == vout) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
     if (!h->scratch) {
         int rc = smt_malloc((void **)&h->scratch, (size_t)h->H * h->W * h->D * 4);
         if (rc != SMT_OK) return rc;

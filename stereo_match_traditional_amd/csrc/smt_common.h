@@ -28,6 +28,21 @@ extern thread_local int g_smt_last_hip;
 
 static inline hipStream_t smt_stream(void *s) { return (hipStream_t)s; }
 
+// Every handle remembers the device it was created on; its entry points make that device current for
+// the duration of the call and restore the caller's afterwards (one host thread may drive several GPUs).
+struct smt_dev_guard {
+    int prev = -1;
+    explicit smt_dev_guard(int dev)
+    {
+        int cur = -1;
+        if (dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~smt_dev_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    smt_dev_guard(const smt_dev_guard &) = delete;
+    smt_dev_guard &operator=(const smt_dev_guard &) = delete;
+};
+static inline int smt_current_device() { int d = -1; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+
 #ifdef __HIPCC__
 constexpr int WAVE = 64;
 

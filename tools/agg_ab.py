@@ -12,6 +12,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--variants", default="3,4")
 ap.add_argument("--sws", default="8,16,32,64")
 ap.add_argument("--views", default="L,R")
+ap.add_argument("--sweeps", default="0")
 ap.add_argument("--size", default="1080,1920,192")
 a = ap.parse_args()
 DEV = "cuda:0"
@@ -41,11 +42,14 @@ for name, img, vol in (("L", Lu, adc.GetPtrLeft()), ("R", Ru, adc.GetPtrRight())
     res[f"{name}_v0_sw16"] = timed(lambda: fn(vol, ref), a.reps)
     for v in [int(x) for x in a.variants.split(",")]:
         ca.set_variant(v)
-        for sw in [int(x) for x in a.sws.split(",")]:
-            ca.set_strip_width(sw)
-            out.zero_()
-            res[f"{name}_v{v}_sw{sw}"] = timed(lambda: fn(vol, out), a.reps)
-            if not torch.equal(out.view(torch.int32), ref.view(torch.int32)):
-                res[f"{name}_v{v}_sw{sw}_MISMATCH"] = True
+        for swp in [int(x) for x in a.sweeps.split(",")]:
+            ca.set_sweep(swp)
+            for sw in [int(x) for x in a.sws.split(",")]:
+                ca.set_strip_width(sw)
+                out.zero_()
+                key = f"{name}_v{v}_sweep{swp}_sw{sw}"
+                res[key] = timed(lambda: fn(vol, out), a.reps)
+                if not torch.equal(out.view(torch.int32), ref.view(torch.int32)):
+                    res[key + "_MISMATCH"] = True
     ca.close()
 print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()}))

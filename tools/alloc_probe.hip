@@ -70,8 +70,18 @@ int main()
             }
             float mhz = 0;
             if (!ratio.empty()) { std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end()); mhz = ratio[ratio.size() / 2]; }
-            printf("round %d trial %2d  a=%p b=%p  store-only %.4f ms  %.0f GB/s  sclk %.0f MHz\n", round, trial, (void *)a, (void *)b,
-                   ms / 40, 2.0 * V * 4 / (ms / 40 * 1e-3) / 1e9, mhz);
+            // each volume by itself, written as both "views" of a pair-sized launch split in two halves:
+            // (a-first-half, a-second-half) -- is slow/fast a property of one buffer or of the pair?
+            float msa, msb;
+            float *a2 = a + V / 2, *b2 = b + V / 2;
+            hipEventRecord(e0);
+            for (int k = 0; k < 40; k++) hipLaunchKernelGGL(k_rows_xcd<3>, dim3(nblk / 2), dim3(256), 0, 0, a, a2, H / 2, W, nbx, (unsigned long long *)nullptr);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&msa, e0, e1);
+            hipEventRecord(e0);
+            for (int k = 0; k < 40; k++) hipLaunchKernelGGL(k_rows_xcd<3>, dim3(nblk / 2), dim3(256), 0, 0, b, b2, H / 2, W, nbx, (unsigned long long *)nullptr);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&msb, e0, e1);
+            printf("round %d trial %2d  a=%p b=%p  store-only %.4f ms  %.0f GB/s  sclk %.0f MHz  a-alone %.4f b-alone %.4f (x2 for the pair)\n", round, trial, (void *)a, (void *)b,
+                   ms / 40, 2.0 * V * 4 / (ms / 40 * 1e-3) / 1e9, mhz, msa / 40, msb / 40);
             fflush(stdout);
         }
         for (float *p : keep) hipFree(p);
