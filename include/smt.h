@@ -234,9 +234,10 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
                                              plane since the previous status call / reset / arms */
-/* Test / tuning hook: which aggregation kernel runs.  4 = 2x8 pixels per wave, every tap of the
+/* Test / tuning hook: which aggregation kernel runs.  6 = 2x8 pixels per wave, every tap of the
  * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
- * a member skipped (default), 5 = the same without the skip, 3 = 1x8 pixels without the skip,
+ * a member skipped, flag rows fetched one tap ahead (default), 4 = the same with the flags fetched per
+ * live group, 5 = 4 without the skip, 3 = 1x8 pixels without the skip,
  * 0 = four adjacent pixels per wave (mask switch), 1 = plain one-pixel-per-wave walk,
  * 2 = pipelined one-pixel-per-wave walk.  All produce identical bits. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);
@@ -261,6 +262,19 @@ int smt_cblsm_ad(const uint8_t *L, const uint8_t *R, int H, int W, int D, int vi
 int smt_cblsm_choose_arm_length(int dir, const int *own_arm, const int *other_vertical_arm,
                                 const int *armRL, const int *armRR, int H, int W, int D,
                                 int *arm_volume, void *stream);
+
+/* CBLSM.h:1087-1126 costAggregationNew with :969-1045 ComputeLocalValue (dead experiment, call site commented
+ * out at CBLSM.cpp:113-116): cost[p][d] = | value(left image, arms at slot 0) - value(right image shifted by
+ * d, arms at slot d) |, value = sum over rows [-Up, Down] of the row's pixels in [j-L-d, j+R-d) divided by
+ * the sum of (L+R+1) -- the reference counts one pixel more per row than it adds (:1021, :1034), R+1 for
+ * a left-clipped row (:1011) and 1 for a row clipped to column 0 (:996); all reproduced.
+ *   Lp, Rp      uint8 [H+2w][W+2w], replicate-padded by w = winSize+1
+ *   armvol*     int32 [H][W][D] from smt_cblsm_choose_arm_length (dir 0, 1, 2, 3); Up / Down must keep
+ *               rows inside the image (rows outside are skipped)
+ *   cost        float32 [H][W][D] out. */
+int smt_cblsm_cost_aggregation_new(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSize,
+                                   const int *armvolL, const int *armvolR, const int *armvolUp,
+                                   const int *armvolDown, float *cost, void *stream);
 
 /* =====================================================================================
  * Scanline optimiser                  replaces class ScanlineOptimizer
@@ -394,6 +408,22 @@ int smt_asw_crosscheck(const float *dispL, const float *dispR, int H, int W, uin
 /* =====================================================================================
  * Either side of the path: input staging and the first post-filter
  * ===================================================================================== */
+/* Image files, HOST side (no GPU work): what the reference's drivers do with cv::imread(path) /
+ * cv::imwrite(path, img) (AD-CensusV1/main.cpp:16-17, :115-117; SADmain.cpp:28-29; ASWeight.cpp:11-12),
+ * without OpenCV / libpng / zlib.
+ * smt_image_read: 8-bit PNG (colour types 0, 2, 3, 4, 6; bit depths 1-16 -- 16-bit samples keep their
+ * high byte; alpha dropped; palettes expanded; non-interlaced) and binary PGM / PPM (P5 / P6).
+ *   want_channels  3: always 3-channel B, G, R like cv::imread's default flag (a gray file is replicated);
+ *                  1: gray (a colour file goes through the BGR2GRAY rule of smt_bgr2gray);
+ *                  0: as stored (1 or 3).
+ *   *pixels is malloc'd [H][W][channels]; release it with smt_image_free.
+ * smt_image_write: by extension -- .png (8-bit gray or colour, filter 0, stored deflate blocks: valid,
+ * uncompressed), .pgm / .ppm / .pnm; channels 1 or 3 (B, G, R in memory).
+ * Both return SMT_ERR_ARG for unreadable / malformed / unsupported files. */
+int smt_image_read(const char *path, int want_channels, uint8_t **pixels, int *H, int *W, int *channels);
+int smt_image_free(uint8_t *pixels);
+int smt_image_write(const char *path, const uint8_t *pixels, int H, int W, int channels);
+
 /* cvtColor(CV_BGR2GRAY) as the drivers call it (AD-CensusV1/main.cpp:19-20): OpenCV 3.1.0's
  * 8-bit fixed-point rule (1868 B + 9617 G + 4899 R + 8192) >> 14.  bgr uint8 [H][W][3]. */
 int smt_bgr2gray(const uint8_t *bgr, int H, int W, uint8_t *gray, void *stream);

@@ -364,3 +364,15 @@ def choose_arm_length(dirn, own, vert, RL, RR, D):
     lib().orc_choose_arm_length(int(dirn), _p(own), _p(vert) if vert is not None else None, _p(RL), _p(RR),
                                 row, col, int(D), _p(vol))
     return vol
+
+
+def cblsm_cost_aggregation_new(Lp, Rp, winSize, armL, armR, armUp, armDown):
+    """costAggregationNew (CBLSM.h:1087-1126) on padded images + int32 [H][W][D] arm volumes."""
+    Lp = _c(Lp, np.uint8); Rp = _c(Rp, np.uint8)
+    Hp, Wp = Lp.shape
+    vols = [_c(a, np.int32) for a in (armL, armR, armUp, armDown)]
+    H, W, D = vols[0].shape
+    assert H == Hp - 2 * (winSize + 1) and W == Wp - 2 * (winSize + 1)
+    cost = np.empty((H, W, D), np.float32)
+    lib().orc_cblsm_cost_aggregation_new(_p(Lp), _p(Rp), Hp, Wp, int(winSize), *[_p(v) for v in vols], int(D), _p(cost))
+    return cost

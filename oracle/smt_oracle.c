@@ -1098,6 +1098,62 @@ ORC_API void orc_choose_arm_length(int dir, const int *own, const int *vert, con
             }
 }
 
+/* CBLSM.h:969-1045 ComputeLocalValue + :1087-1126 costAggregationNew (dead experiments, SURVEY 8f n4;
+ * call site commented out, CBLSM.cpp:113-116).  Lp / Rp: images replicate-padded by w = winSize + 1,
+ * [Hp][Wp]; arm volumes int32 [H][W][D] with H = Hp - 2w, W = Wp - 2w (`_col_`).  The OpenCV calls are ROI
+ * sums of 8-bit pixels (cv::sum -> double, exact); `value` is a float that takes each row's double sum
+ * (:1004, :1012, :1022, :1035), the mean divides by a count that is L+R+1 per row although the ROI holds
+ * L+R pixels (:1021, :1034 -- "a small error", says the author) and R+1 for a left-clipped row (:1011).
+ * Rows or columns that would leave the padded image (impossible with arm volumes from
+ * chooseArmLength*) are skipped.  The `#pragma omp parallel for` on the row loop (:982) races on
+ * count / value; sequential semantics are the specification. */
+static float orc_cblsm_local_value(const uint8_t *img, int Hp, int Wp, int i, int j, int Up, int Down, int w,
+                                   const int *LArm, const int *RArm, int H, int W, int D, int d)
+{
+    int count = 0;
+    float value = 0;
+    const int ptrj = j - w;
+    for (int r = -Up; r <= Down; r++) {
+        int ptr_i = i - w + r;
+        if (ptr_i < 0 || ptr_i >= H || i + r < 0 || i + r >= Hp) continue;
+        int L = LArm[((size_t)ptr_i * W + ptrj) * D + d];
+        int R = RArm[((size_t)ptr_i * W + ptrj) * D + d];
+        int c0, c1;
+        if (d > 0) {
+            if (j - L - d < 0) {
+                if (j + R - d <= 0) { c0 = 0; c1 = 1; count += 1; }                /* :994-997 */
+                else { c0 = 0; c1 = j + R - d; count += R + 1; }                   /* :1006-1009 */
+            } else { c0 = j - L - d; c1 = j + R - d; count += L + R + 1; }         /* :1018-1021 */
+        } else {
+            if (L == 0 && R == 0) { c0 = j; c1 = j + 1; }                          /* :1029-1031 */
+            else { c0 = j - L; c1 = j + R; }                                       /* :1033-1035 */
+            count += L + R + 1;
+        }
+        if (c0 < 0) c0 = 0;
+        if (c1 > Wp) c1 = Wp;
+        double sum = 0;
+        for (int c = c0; c < c1; c++) sum += img[(size_t)(i + r) * Wp + c];
+        value = (float)((double)value + sum);
+    }
+    return value / count;                                                          /* :1041 */
+}
+
+ORC_API void orc_cblsm_cost_aggregation_new(const uint8_t *Lp, const uint8_t *Rp, int Hp, int Wp, int winSize,
+                                            const int *armL, const int *armR, const int *armUp, const int *armDown,
+                                            int D, float *cost)
+{
+    const int w = winSize + 1, H = Hp - 2 * w, W = Wp - 2 * w;
+    for (int i = w; i < Hp - w; ++i)
+        for (int j = w; j < Wp - w; ++j)
+            for (int d = 0; d < D; d++) {
+                const size_t k = ((size_t)(i - w) * W + (j - w)) * D + d;
+                const int Up = armUp[k], Down = armDown[k];
+                float lv = orc_cblsm_local_value(Lp, Hp, Wp, i, j, Up, Down, w, armL, armR, H, W, D, 0);   /* :1111 */
+                float rv = orc_cblsm_local_value(Rp, Hp, Wp, i, j, Up, Down, w, armL, armR, H, W, D, d);   /* :1113 */
+                cost[k] = fabsf(lv - rv);                                                                /* :1114-1118 */
+            }
+}
+
 /* FNV-1a 64 over raw bytes: fixture hashes */
 ORC_API uint64_t orc_fnv1a(const void *p, size_t n)
 {

@@ -11,11 +11,11 @@ import torch
 from . import _lib
 from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
-__all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
+__all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "costAggregationNew", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
-           "to_float", "MedianFilter", "RemoveSpeckles"]
+           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite"]
 
 
 def current_stream_ptr():
@@ -295,7 +295,8 @@ class CrossArmAggregation:
         wta(AggredCostVolume, disp)
 
     def set_variant(self, variant):
-        """4 = 2x8 pixels per wave sharing union taps (default), 5 = same without group skip, 3 = 1x8,
+        """6 = 2x8 pixels per wave sharing union taps, flags prefetched (default), 4 = flags per live group,
+        5 = no group skip, 3 = 1x8,
         0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
 
@@ -363,6 +364,24 @@ def chooseArmLengthUp(ArmLUp, ArmLDown, ArmRUp, ArmRDown, ArmRL, ArmRR, dispRang
 def chooseArmLengthDown(ArmLUp, ArmLDown, ArmRUp, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col):
     """CBLSM.h:195-236."""
     return _choose_arm(3, ArmLDown, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col)
+
+
+def costAggregationNew(leftImage, rightImage, CostVolume, ArmvolumeL, ArmvolumeR, ArmvolumeUp, ArmvolumeDown, dispRange,
+                       _row_, _col_, winSize):
+    """CBLSM.h:1087-1126 (argument order of the reference).  Padded uint8 images, int32 [row][col][D] arm
+    volumes, float32 [row][col][D] CostVolume (allocated when None)."""
+    w = winSize + 1
+    _dev(leftImage, torch.uint8, (_row_ + 2 * w, _col_ + 2 * w), "leftImage")
+    _dev(rightImage, torch.uint8, (_row_ + 2 * w, _col_ + 2 * w), "rightImage")
+    for a in (ArmvolumeL, ArmvolumeR, ArmvolumeUp, ArmvolumeDown):
+        _dev(a, torch.int32, (_row_, _col_, dispRange), "arm volume")
+    if CostVolume is None:
+        CostVolume = torch.empty((_row_, _col_, dispRange), dtype=torch.float32, device=leftImage.device)
+    _dev(CostVolume, torch.float32, (_row_, _col_, dispRange), "CostVolume")
+    check(lib().smt_cblsm_cost_aggregation_new(_ptr(leftImage), _ptr(rightImage), _row_, _col_, int(dispRange), int(winSize),
+                                               _ptr(ArmvolumeL), _ptr(ArmvolumeR), _ptr(ArmvolumeUp), _ptr(ArmvolumeDown),
+                                               _ptr(CostVolume), current_stream_ptr()), "smt_cblsm_cost_aggregation_new")
+    return CostVolume
 
 
 # ======================================================================================
@@ -673,3 +692,31 @@ def RemoveSpeckles(disparity_map, width, height, diff_insame, min_speckle_aera, 
     check(lib().smt_remove_speckles(_ptr(disparity_map), width, height, int(diff_insame), C.c_uint(min_speckle_aera),
                                     int(invalid_val), current_stream_ptr()), "smt_remove_speckles")
     return disparity_map
+
+
+# ======================================================================================
+# Image files (host side): imread / imwrite of the reference's drivers
+# ======================================================================================
+def imread(path, want_channels=3):
+    """cv::imread(path) (main.cpp:16-17): numpy uint8 [H][W][3] in B, G, R order by default;
+    want_channels=1 gray, 0 as stored.  PNG / PGM / PPM, decoded by libsmt_hip.so's own reader."""
+    import numpy as np
+    p = C.POINTER(C.c_uint8)()
+    H, W, ch = C.c_int(), C.c_int(), C.c_int()
+    check(lib().smt_image_read(str(path).encode(), int(want_channels), C.byref(p), C.byref(H), C.byref(W), C.byref(ch)),
+          "smt_image_read")
+    try:
+        a = np.ctypeslib.as_array(p, shape=(H.value * W.value * ch.value,)).copy()
+    finally:
+        lib().smt_image_free(p)
+    return a.reshape(H.value, W.value) if ch.value == 1 else a.reshape(H.value, W.value, ch.value)
+
+
+def imwrite(path, img):
+    """cv::imwrite(path, img) (main.cpp:115-117) for uint8 [H][W] or [H][W][3] (B, G, R) arrays /
+    CPU tensors; .png, .pgm, .ppm."""
+    import numpy as np
+    a = np.ascontiguousarray(img.cpu().numpy() if isinstance(img, torch.Tensor) else img, dtype=np.uint8)
+    H, W = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    check(lib().smt_image_write(str(path).encode(), a.ctypes.data_as(C.c_void_p), H, W, ch), "smt_image_write")

@@ -891,6 +891,58 @@ __global__ void __launch_bounds__(NT) k_choose_arm(int dir, const int *__restric
     out[k] = save;
 }
 
+// CBLSM.h:969-1045 ComputeLocalValue: mean-like value over a region whose rows carry their own
+// per-hypothesis horizontal arms (see smt.h for the count quirk).  `value` is a float that absorbs each row's
+// exact integer sum through a double add, as `value = value + sum(image)[0]` does.
+__device__ __forceinline__ float cblsm_local_value(const uint8_t *__restrict__ img, int Hp, int Wp, int i, int j, int Up,
+                                                   int Down, int w, const int *__restrict__ LArm,
+                                                   const int *__restrict__ RArm, int H, int W, int D, int d)
+{
+    int count = 0;
+    float value = 0.0f;
+    const int ptrj = j - w;
+    for (int r = -Up; r <= Down; r++) {
+        const int ptr_i = i - w + r;
+        if (ptr_i < 0 || ptr_i >= H || i + r < 0 || i + r >= Hp) continue;
+        const int L = LArm[((size_t)ptr_i * W + ptrj) * D + d], R = RArm[((size_t)ptr_i * W + ptrj) * D + d];
+        int c0, c1;
+        if (d > 0) {
+            if (j - L - d < 0) {
+                if (j + R - d <= 0) { c0 = 0; c1 = 1; count += 1; }
+                else { c0 = 0; c1 = j + R - d; count += R + 1; }
+            } else { c0 = j - L - d; c1 = j + R - d; count += L + R + 1; }
+        } else {
+            if (L == 0 && R == 0) { c0 = j; c1 = j + 1; }
+            else { c0 = j - L; c1 = j + R; }
+            count += L + R + 1;
+        }
+        c0 = max(c0, 0); c1 = min(c1, Wp);
+        int sum = 0;                                   // <= 4096 pixels of 255: exact
+        const uint8_t *row = img + (size_t)(i + r) * Wp;
+        for (int c = c0; c < c1; c++) sum += row[c];
+        value = (float)((double)value + (double)sum);
+    }
+    return value / (float)count;
+}
+
+// costAggregationNew (CBLSM.h:1087-1126): one thread per (pixel, d)
+__global__ void __launch_bounds__(NT) k_cblsm_cost_agg_new(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp,
+                                                           int Hp, int Wp, int w, const int *__restrict__ armL,
+                                                           const int *__restrict__ armR, const int *__restrict__ armUp,
+                                                           const int *__restrict__ armDown, int D, float *__restrict__ cost)
+{
+    const int H = Hp - 2 * w, W = Wp - 2 * w;
+    const size_t k = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (k >= (size_t)H * W * D) return;
+    const int d = (int)(k % D);
+    const size_t p = k / D;
+    const int j = (int)(p % W) + w, i = (int)(p / W) + w;
+    const int Up = armUp[k], Down = armDown[k];
+    const float lv = cblsm_local_value(Lp, Hp, Wp, i, j, Up, Down, w, armL, armR, H, W, D, 0);
+    const float rv = cblsm_local_value(Rp, Hp, Wp, i, j, Up, Down, w, armL, armR, H, W, D, d);
+    cost[k] = fabsf(lv - rv);
+}
+
 }  // namespace
 
 struct smt_crossarm {
@@ -926,7 +978,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
-    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 16; h->variant = 4;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 16; h->variant = 6;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
@@ -1244,6 +1296,21 @@ SMT_API int smt_cblsm_choose_arm_length(int dir, const int *own_arm, const int *
     const size_t V = (size_t)H * W * D;
     hipLaunchKernelGGL(k_choose_arm, dim3((unsigned)((V + NT - 1) / NT)), dim3(NT), 0, smt_stream(stream), dir, own_arm,
                        other_vertical_arm, armRL, armRR, H, W, D, arm_volume);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_cblsm_cost_aggregation_new(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSize,
+                                           const int *armvolL, const int *armvolR, const int *armvolUp,
+                                           const int *armvolDown, float *cost, void *stream)
+{
+    if (!Lp || !Rp || !armvolL || !armvolR || !armvolUp || !armvolDown || !cost || H <= 0 || W <= 0 || D <= 0 ||
+        winSize < 0)
+        return SMT_ERR_ARG;
+    const int w = winSize + 1;
+    const size_t V = (size_t)H * W * D;
+    hipLaunchKernelGGL(k_cblsm_cost_agg_new, dim3((unsigned)((V + NT - 1) / NT)), dim3(NT), 0, smt_stream(stream), Lp, Rp,
+                       H + 2 * w, W + 2 * w, w, armvolL, armvolR, armvolUp, armvolDown, D, cost);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }

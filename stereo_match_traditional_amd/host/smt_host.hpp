@@ -79,14 +79,16 @@ public:
     float *DevicePtrLeft() { float *p; check(smt_adcensus_volume(h_, SMT_VIEW_LEFT, &p), "volume"); return p; }
     float *DevicePtrRight() { float *p; check(smt_adcensus_volume(h_, SMT_VIEW_RIGHT, &p), "volume"); return p; }
     // GetPtrLeft/Right: host copy of the cost volume, valid for the object's life like the reference's
+    // (bad input -- a pixel that is not an integer in 0..255 -- is reported here, at the first point
+    // where the reference's caller would consume the volume: smt_adcensus_status)
     float *GetPtrLeft()
     {
-        if (!validL_) { fetch(DevicePtrLeft(), hostL_); validL_ = true; }
+        if (!validL_) { check(smt_adcensus_status(h_), "smt_adcensus_status"); fetch(DevicePtrLeft(), hostL_); validL_ = true; }
         return hostL_.data();
     }
     float *GetPtrRight()
     {
-        if (!validR_) { fetch(DevicePtrRight(), hostR_); validR_ = true; }
+        if (!validR_) { check(smt_adcensus_status(h_), "smt_adcensus_status"); fetch(DevicePtrRight(), hostR_); validR_ = true; }
         return hostR_.data();
     }
     void WTA(float *leftdisp, float *rightDisp)
@@ -124,6 +126,7 @@ public:
         smt_crossarm_default_params(&p);
         p.tau = tao;
         check(smt_crossarm_create(row, col, dispRange, &p, &h_), "smt_crossarm_create");
+        started_ = false;
     }
     // The four Compute*ArmLength(const Mat&) calls of main.cpp:69-72 always come together and in
     // this order (the threshold state chains through them), so they are one call here.
@@ -133,6 +136,22 @@ public:
         img.upload(image);
         check(smt_crossarm_arms(h_, img.get(), channels), "smt_crossarm_arms");
         check(smt_stream_sync(nullptr), "sync");
+    }
+    // The reference's four calls one by one (CrossArm.h:15-18), for callers that run a subset or another
+    // order; the sticky threshold is whatever the previous call left.  Initialize resets it.
+    void ComputeLeftArmLength(const unsigned char *image, int channels) { arm_dir(image, channels, 0); }
+    void ComputeRightArmLength(const unsigned char *image, int channels) { arm_dir(image, channels, 1); }
+    void ComputeTopArmLength(const unsigned char *image, int channels) { arm_dir(image, channels, 2); }
+    void ComputeButtonArmLength(const unsigned char *image, int channels) { arm_dir(image, channels, 3); }
+    // CrossArm.cpp:104-145 (declared in CrossArm.h:19, never called): exclusive upper bounds
+    void Aggregation(float *dispVolume, float *aggregatedCostVolume)
+    {
+        const size_t V = (size_t)row_ * col_ * D_;
+        DevBuf<float> in(V), out(V);
+        in.upload(dispVolume);
+        check(smt_crossarm_aggregate(h_, in.get(), out.get(), 2, nullptr), "smt_crossarm_aggregate");
+        out.download(aggregatedCostVolume);
+        check(smt_crossarm_status(h_), "smt_crossarm_status");
     }
     void AggregationVertical(float *dispVolume, float *aggregatedCostVolume)
     {
@@ -156,8 +175,17 @@ public:
         d.download(disp);
     }
 private:
+    void arm_dir(const unsigned char *image, int channels, int dir)
+    {
+        DevBuf<unsigned char> img((size_t)row_ * col_ * channels);
+        img.upload(image);
+        if (!started_) { check(smt_crossarm_reset(h_), "smt_crossarm_reset"); started_ = true; }
+        check(smt_crossarm_arm_dir(h_, img.get(), channels, dir), "smt_crossarm_arm_dir");
+        check(smt_stream_sync(nullptr), "sync");
+    }
     smt_crossarm *h_ = nullptr;
     int row_ = 0, col_ = 0, D_ = 0;
+    bool started_ = false;
 };
 
 // ------------------------------------------------------------------ ScanlineOptimizer.h:8-34
@@ -211,6 +239,26 @@ inline void LeftRightConsistency(int col, int row, int gate, float *leftDisp, fl
     check(smt_lrcheck_lists(h.data(), row, col, o.data(), &no, m.data(), &nm), "smt_lrcheck_lists");
     occlusion.clear(); mismatch.clear();
     for (int k = 0; k < no; k++) occlusion.emplace_back(o[2 * k], o[2 * k + 1]);
+    for (int k = 0; k < nm; k++) mismatch.emplace_back(m[2 * k], m[2 * k + 1]);
+}
+
+// ------------------------------------------------------------------ PostProcessing.h:10 (no call site)
+inline void LeftAndRightConsistency(float *leftDisp, float *rightDisp, float *lastDisp, int col, int row, float gate,
+                                    std::vector<std::pair<int, int>> &occlusion,
+                                    std::vector<std::pair<int, int>> &mismatch)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<float> dl(n), dr(n), last(n);
+    DevBuf<uint8_t> cls(n);
+    dl.upload(leftDisp); dr.upload(rightDisp);
+    check(smt_lrcheck_variant(dl.get(), dr.get(), last.get(), row, col, gate, cls.get(), nullptr, nullptr), "smt_lrcheck_variant");
+    last.download(lastDisp);
+    std::vector<uint8_t> h(n);
+    cls.download(h.data());
+    std::vector<int> o(2 * n), m(2 * n);
+    int no = 0, nm = 0;
+    check(smt_lrcheck_lists(h.data(), row, col, o.data(), &no, m.data(), &nm), "smt_lrcheck_lists");
+    for (int k = 0; k < no; k++) occlusion.emplace_back(o[2 * k], o[2 * k + 1]);     // the reference appends (:44, :47)
     for (int k = 0; k < nm; k++) mismatch.emplace_back(m[2 * k], m[2 * k + 1]);
 }
 
@@ -387,6 +435,86 @@ inline void RemoveSpeckles(float *disparity_map, const int &width, const int &he
     check(smt_remove_speckles(a.get(), width, height, diff_insame, min_speckle_aera, invalid_val, nullptr),
           "smt_remove_speckles");
     a.download(disparity_map);
+}
+
+// ------------------------------------------------------------------ drivers' image handling
+// imread(path) (AD-CensusV1/main.cpp:16-17): 3-channel B, G, R;  cvtColor(.., CV_BGR2GRAY) (:19-20);
+// imwrite(path, img) (:115-117).  Host-side decoding / encoding is libsmt_hip.so's own (PNG, PGM, PPM).
+struct Image {
+    int rows = 0, cols = 0, channels = 0;
+    std::vector<unsigned char> data;
+};
+inline Image imread(const std::string &path, int want_channels = 3)
+{
+    Image im;
+    uint8_t *p = nullptr;
+    check(smt_image_read(path.c_str(), want_channels, &p, &im.rows, &im.cols, &im.channels), "smt_image_read");
+    im.data.assign(p, p + (size_t)im.rows * im.cols * im.channels);
+    smt_image_free(p);
+    return im;
+}
+inline void imwrite(const std::string &path, const unsigned char *data, int rows, int cols, int channels)
+{
+    check(smt_image_write(path.c_str(), data, rows, cols, channels), "smt_image_write");
+}
+inline Image cvtColorBGR2GRAY(const Image &bgr)
+{
+    if (bgr.channels != 3) throw std::runtime_error("cvtColorBGR2GRAY: 3-channel image expected");
+    const size_t n = (size_t)bgr.rows * bgr.cols;
+    DevBuf<unsigned char> in(n * 3), out(n);
+    in.upload(bgr.data.data());
+    check(smt_bgr2gray(in.get(), bgr.rows, bgr.cols, out.get(), nullptr), "smt_bgr2gray");
+    Image g;
+    g.rows = bgr.rows; g.cols = bgr.cols; g.channels = 1; g.data.resize(n);
+    out.download(g.data.data());
+    return g;
+}
+
+// ------------------------------------------------------------------ config 5: a batch over the node's GPUs
+// One host thread, one smt_adcensus handle per device (smt_adcensus_create_on); pair b goes to device
+// b % G as a contiguous block per device; no data-path exchange between devices (pairs are independent,
+// SURVEY 8e) -- the maps come back to the host buffers directly.  L, R: [pairs][row][col] float (integer
+// valued); dispL, dispR: [pairs][row][col] float out.  Returns the number of devices used.
+inline int AD_Census_batch_all_devices(const float *L, const float *R, int pairs, int dispRange, int row, int col,
+                                       float sigmaC, float sigmaS, float *dispL, float *dispR, int max_devices = 0)
+{
+    int G = 0;
+    check(smt_device_count(&G), "smt_device_count");
+    if (max_devices > 0 && G > max_devices) G = max_devices;
+    if (G > pairs) G = pairs;
+    if (G <= 0) throw std::runtime_error("no device / empty batch");
+    const size_t n = (size_t)row * col;
+    struct Dev { smt_adcensus *h = nullptr; void *stream = nullptr; float *L = nullptr, *R = nullptr, *dl = nullptr, *dr = nullptr; int start = 0, count = 0; };
+    std::vector<Dev> dev(G);
+    const int q = pairs / G, r = pairs % G;
+    for (int g = 0; g < G; g++) {
+        Dev &d = dev[g];
+        d.count = q + (g < r ? 1 : 0);
+        d.start = g * q + (g < r ? g : r);
+        check(smt_set_device(g), "smt_set_device");
+        check(smt_adcensus_create_on(g, row, col, dispRange, sigmaC, sigmaS, &d.h), "smt_adcensus_create_on");
+        check(smt_stream_create(&d.stream), "smt_stream_create");
+        check(smt_adcensus_set_stream(d.h, d.stream), "smt_adcensus_set_stream");
+        const size_t bytes = (size_t)d.count * n * sizeof(float);
+        check(smt_malloc((void **)&d.L, bytes), "smt_malloc"); check(smt_malloc((void **)&d.R, bytes), "smt_malloc");
+        check(smt_malloc((void **)&d.dl, bytes), "smt_malloc"); check(smt_malloc((void **)&d.dr, bytes), "smt_malloc");
+        check(smt_memcpy_h2d(d.L, L + (size_t)d.start * n, bytes, d.stream), "h2d");
+        check(smt_memcpy_h2d(d.R, R + (size_t)d.start * n, bytes, d.stream), "h2d");
+        // asynchronous on the device's own stream: all devices compute concurrently
+        check(smt_adcensus_compute_batch(d.h, d.L, d.R, d.count, SMT_VIEW_BOTH, d.dl, d.dr), "smt_adcensus_compute_batch");
+        check(smt_memcpy_d2h(dispL + (size_t)d.start * n, d.dl, bytes, d.stream), "d2h");
+        check(smt_memcpy_d2h(dispR + (size_t)d.start * n, d.dr, bytes, d.stream), "d2h");
+    }
+    for (int g = 0; g < G; g++) {
+        Dev &d = dev[g];
+        check(smt_set_device(g), "smt_set_device");
+        check(smt_adcensus_status(d.h), "smt_adcensus_status");        // synchronises the device's stream
+        smt_free(d.L); smt_free(d.R); smt_free(d.dl); smt_free(d.dr);
+        smt_adcensus_destroy(d.h);
+        smt_stream_destroy(d.stream);
+    }
+    check(smt_set_device(0), "smt_set_device");
+    return G;
 }
 
 }  // namespace smt

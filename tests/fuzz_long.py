@@ -41,7 +41,7 @@ while time.time() - t0 < 150:
     ref, oob = O.aggregate_rect(vol, arms, order)
     ca = smt.CrossArmAggregation().Initialize(H, W, tau, D, DEV, style="adcensus" if chain else "cblsm", quirks=QUIRK_FIX_RIGHT_ARM_STRIDE)
     ca.ComputeArmLengths(T(img))
-    for variant in (3, 4, 5):
+    for variant in (3, 4, 5, 6):
         ca.set_variant(variant); ca.set_strip_width(int(rng.choice([8, 16, 32, 64])))
         out = torch.empty((H, W, D), device=DEV); disp = torch.empty((H, W), device=DEV)
         (ca.AggregationVertical if order == 0 else ca.costAggregationV5)(T(vol), out, disp)

@@ -48,3 +48,53 @@ def test_matchers_main_counterpart(smt, O):
                 "speckles": O.remove_speckles(al, 1, 30, -(2 ** 31))})
     for k, v in exp.items():
         assert got[k] == f"{O.fnv1a(v):016x}", k
+
+
+def test_main_cpp_counterpart_from_image_files(smt, O, tmp_path):
+    """The file path of main.cpp:16-20, :115-117: imread (own PNG decoder, 3-channel BGR) -> cvtColor
+    BGR2GRAY on the device -> the pipeline -> imwrite, on a colour PNG pair written here."""
+    import struct
+    import zlib
+
+    def png(path, bgr):
+        H, W, _ = bgr.shape
+        raw = b"".join(b"\x00" + bgr[r, :, ::-1].tobytes() for r in range(H))
+        ch = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+        path.write_bytes(b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) +
+                         ch(b"IDAT", zlib.compress(raw, 6)) + ch(b"IEND", b""))
+
+    H, W, D = 48, 120, 32
+    L, R = O.synth_pair(H, W, D, 7)
+    Lb, Rb = O.synth_bgr(L, 3), O.synth_bgr(R, 4)
+    png(tmp_path / "l.png", Lb)
+    png(tmp_path / "r.png", Rb)
+    r = subprocess.run([EXE, "--images", str(tmp_path / "l.png"), str(tmp_path / "r.png"), str(D), str(tmp_path / "d.png")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.split() for line in r.stdout.strip().splitlines())
+    Lg, Rg = O.bgr2gray(Lb), O.bgr2gray(Rb)
+    assert got["gray_left"] == f"{O.fnv1a(Lg):016x}" and got["gray_right"] == f"{O.fnv1a(Rg):016x}"
+    cl = O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 0)
+    cr = O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 1)
+    al, _ = O.aggregate_rect(cl, O.arms_all(Lg), 0)
+    ar, _ = O.aggregate_rect(cr, O.arms_all(Rg), 0)
+    dl, dr = O.wta(O.scanline(al, Lg.astype(np.float32), 10, 150)), O.wta(ar)
+    lr, cls, no, nm = O.lrcheck(dl, dr, 2)
+    assert got["cost_left"] == f"{O.fnv1a(cl):016x}" and got["lr_left"] == f"{O.fnv1a(lr):016x}"
+    shown = smt.imread(tmp_path / "d.png", 0)
+    exp = np.where(np.isfinite(lr), (lr * 255.0 / (D - 1) + 0.5).astype(np.uint8), 0).astype(np.uint8)
+    assert np.array_equal(shown, exp)
+
+
+def test_batch_over_all_visible_devices(smt, O):
+    """host/smt_host.hpp AD_Census_batch_all_devices (one handle per device, smt_adcensus_create_on): on this
+    box one device; 5 pairs, every map against the oracle."""
+    H, W, D, P = 40, 100, 64, 5
+    r = subprocess.run([EXE, "--batch", str(P), str(H), str(W), str(D)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == P
+    for b, l in enumerate(lines):
+        Lg, Rg = O.synth_pair(H, W, D, 1000 + b)
+        assert l[3] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 0))):016x}", b
+        assert l[5] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 1))):016x}", b

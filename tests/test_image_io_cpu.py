@@ -1,0 +1,138 @@
+"""Host-side image reader / writer of libsmt_hip.so (cv::imread / cv::imwrite of the
+reference's drivers, main.cpp:16-17, :115-117) against PNG files built here with Python's zlib -- every
+colour type, bit depth and scanline filter, real deflate streams (dynamic Huffman) as well as stored
+blocks -- and its writer's output decoded here.  No GPU."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+def _chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+
+def _paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+
+def make_png(rows, W, H, ctype, depth, bpp, filters, level=6, plte=None, split=1):
+    """rows: list of H byte strings (packed samples).  Applies filter type filters[r % len] per row."""
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for r, row in enumerate(rows):
+        ft = filters[r % len(filters)]
+        out = bytearray([ft])
+        for x, v in enumerate(row):
+            a = row[x - bpp] if x >= bpp else 0
+            b = prev[x]
+            c = prev[x - bpp] if x >= bpp else 0
+            pred = [0, a, b, (a + b) >> 1, _paeth(a, b, c)][ft]
+            out.append((v - pred) & 0xFF)
+        raw += out
+        prev = row
+    z = zlib.compress(bytes(raw), level)
+    png = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 0))
+    if plte is not None:
+        png += _chunk(b"PLTE", plte)
+    n = max(1, len(z) // split)
+    for k in range(0, len(z), n):                          # several IDAT chunks
+        png += _chunk(b"IDAT", z[k:k + n])
+    return png + _chunk(b"IEND", b"")
+
+
+@pytest.fixture(scope="module")
+def smt():
+    import stereo_match_traditional_amd as pkg
+    from stereo_match_traditional_amd._lib import lib
+    lib()
+    return pkg
+
+
+@pytest.mark.parametrize("level", [0, 1, 9])
+def test_png_gray8_all_filters(smt, tmp_path, level):
+    rng = np.random.default_rng(level)
+    H, W = 37, 53
+    img = (np.add.outer(np.arange(H) * 3, np.arange(W) * 2) % 251 + rng.integers(0, 4, (H, W))).astype(np.uint8)
+    p = tmp_path / "g.png"
+    p.write_bytes(make_png([bytes(r) for r in img], W, H, 0, 8, 1, [0, 1, 2, 3, 4], level, split=3))
+    assert np.array_equal(smt.imread(p, 0), img)
+    assert np.array_equal(smt.imread(p, 1), img)
+    bgr = smt.imread(p)                                   # default: 3-channel like cv::imread
+    assert bgr.shape == (H, W, 3) and all(np.array_equal(bgr[..., c], img) for c in range(3))
+
+
+def test_png_rgb_rgba_16bit_palette_subbyte(smt, tmp_path):
+    rng = np.random.default_rng(5)
+    H, W = 19, 31
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    p = tmp_path / "c.png"
+    p.write_bytes(make_png([bytes(r.reshape(-1)) for r in rgb], W, H, 2, 8, 3, [4, 3, 1, 2, 0]))
+    got = smt.imread(p)
+    assert np.array_equal(got, rgb[..., ::-1])                                         # B, G, R in memory
+    r64 = rgb.astype(np.int64)
+    gray = ((1868 * r64[..., 2] + 9617 * r64[..., 1] + 4899 * r64[..., 0] + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(smt.imread(p, 1), gray)                                      # BGR2GRAY rule
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (H, W, 1), dtype=np.uint8)], axis=2)
+    p.write_bytes(make_png([bytes(r.reshape(-1)) for r in rgba], W, H, 6, 8, 4, [1, 4]))
+    assert np.array_equal(smt.imread(p), rgb[..., ::-1])                               # alpha dropped
+    g16 = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    p.write_bytes(make_png([r.astype(">u2").tobytes() for r in g16], W, H, 0, 16, 2, [2, 4]))
+    assert np.array_equal(smt.imread(p, 0), (g16 >> 8).astype(np.uint8))               # high byte
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (H, W), dtype=np.uint8)
+    packed = [bytes(((r[0::2] << 4) | np.pad(r[1::2], (0, len(r[0::2]) - len(r[1::2])))).astype(np.uint8)) for r in idx]
+    p.write_bytes(make_png(packed, W, H, 3, 4, 1, [0, 1], plte=pal.tobytes()))
+    assert np.array_equal(smt.imread(p), pal[idx][..., ::-1])
+    bits = rng.integers(0, 2, (H, W), dtype=np.uint8)
+    p.write_bytes(make_png([np.packbits(r).tobytes() for r in bits], W, H, 0, 1, 1, [0]))
+    assert np.array_equal(smt.imread(p, 0), bits * 255)
+
+
+def test_pnm_and_writer_round_trips(smt, tmp_path):
+    rng = np.random.default_rng(8)
+    H, W = 23, 41
+    g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    c = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    (tmp_path / "a.pgm").write_bytes(b"P5\n# comment\n%d %d\n255\n" % (W, H) + g.tobytes())
+    assert np.array_equal(smt.imread(tmp_path / "a.pgm", 0), g)
+    (tmp_path / "a.ppm").write_bytes(b"P6 %d %d 255\n" % (W, H) + c.tobytes())
+    assert np.array_equal(smt.imread(tmp_path / "a.ppm"), c[..., ::-1])
+    for name, img in (("o.png", g), ("o3.png", c), ("o.pgm", g), ("o.ppm", c)):
+        smt.imwrite(tmp_path / name, img)
+        back = smt.imread(tmp_path / name, 0)
+        assert np.array_equal(back, img), name
+    # the PNG writer's file as an independent decoder sees it
+    data = (tmp_path / "o3.png").read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n, t = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + body) & 0xFFFFFFFF == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        if t == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert hdr == (W, H, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)
+    assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(H, W, 3), c[..., ::-1])
+
+
+def test_bad_files_are_rejected(smt, tmp_path):
+    from stereo_match_traditional_amd import SmtError
+    good = make_png([bytes(8)] * 4, 8, 4, 0, 8, 1, [0])
+    cases = {"trunc.png": good[:40], "crc.png": good[:20] + bytes([good[20] ^ 1]) + good[21:], "junk.png": b"not a png at all",
+             "short.pgm": b"P5\n4 4\n255\n" + bytes(7)}
+    for name, blob in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        with pytest.raises(SmtError):
+            smt.imread(tmp_path / name)
+    with pytest.raises(SmtError):
+        smt.imread(tmp_path / "missing.png")
+    with pytest.raises(SmtError):
+        smt.imwrite(tmp_path / "x.jpg", np.zeros((2, 2), np.uint8))
