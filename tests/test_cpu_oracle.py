@@ -583,3 +583,12 @@ def test_choose_arm_length_closed_forms_equal_oracle(O):
                 dn[i, j, dd] = s
     assert np.array_equal(O.choose_arm_length(2, LU, RU, RL, RR, D), up)
     assert np.array_equal(O.choose_arm_length(3, LD, RD, RL, RR, D), dn)
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """the CPU restatement built with -fsanitize=address,undefined and run once over every
+    stage on exact-size buffers (oracle/sanitize_main.c, `make -C oracle sanitize`)."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "oracle sanitizer run clean" in r.stdout
