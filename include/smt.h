@@ -217,6 +217,11 @@ int smt_crossarm_reset(smt_crossarm *h);
 int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channels, int dir);
 int smt_crossarm_tau(smt_crossarm *h, int *tau);
 
+/* Test hook: on != 0 computes arms with the first-version kernels (neighbour-by-neighbour walk, an
+ * independent formulation) instead of the bit-mask kernels; they are also what runs when sec_length or
+ * max_length exceeds 63. */
+int smt_crossarm_set_arm_walk(smt_crossarm *h, int on);
+
 /* Borrowed pointers to the int32 [H][W] arm maps (leftLength, rightLength, topLength,
  * buttonLenght; CrossArm.h:30-33). */
 int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, int **bottom);
@@ -365,6 +370,31 @@ int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img_left, const float
  * left,right,top,bottom (struct CrossArm, cross_aggregator.h:17-20). */
 int smt_crossagg_cost(smt_crossagg *h, float **cost);
 int smt_crossagg_arms(smt_crossagg *h, uint8_t **arms);
+
+/* ADCensusOption (CBLSM/adcensus_types.h:45-75), field for field, with its constructor's defaults
+ * (smt_adcensus_option_default).  SURVEY 8f n3.  The reference tree holds this struct and the aggregator it
+ * feeds but NOT the rest of ethan-li-coding/AD-Census (cost computer, its own scanline optimiser with
+ * so_p1 / so_p2 / so_tso, the multi-step refiner with irv_ts / irv_th, filling, discontinuity adjustment,
+ * sub-pixel): those fields are carried, nothing consumes them, and no part of that flow is claimed here
+ * (it would be "parity unpinned" against a source that is not in /root/reference). */
+typedef struct smt_adcensus_option {
+    int32_t min_disparity, max_disparity;
+    int32_t lambda_ad, lambda_census;
+    int32_t cross_L1, cross_L2, cross_t1, cross_t2;
+    float so_p1, so_p2;
+    int32_t so_tso, irv_ts;
+    float irv_th, lrcheck_thres;
+    int32_t do_lr_check, do_filling, do_discontinuity_adjustment;      /* bool in the reference */
+} smt_adcensus_option;
+void smt_adcensus_option_default(smt_adcensus_option *o);
+/* The one caller shape the reference holds for it (CBLSM/CBLSM.cpp:138-143, commented out; WTA :152):
+ *   CrossAggregator a; a.Initialize(col, row, 0, dispRange); a.SetData(bytes_left, bytes_right, dispVolum);
+ *   a.SetParams(option.cross_L1, option.cross_L2, option.cross_t1, option.cross_t2); a.Aggregate(4);
+ *   cost = a.get_cost_ptr();  ComputeDispOringin(cost, disp, ...)
+ * in one call: D = max_disparity - min_disparity, bytes_left uint8 [H][W][3], cost_init / cost_out float32
+ * [H][W][D], disp float32 [H][W] (may be NULL).  Synchronising. */
+int smt_adcensus_option_aggregate(const smt_adcensus_option *o, const uint8_t *bytes_left, const float *cost_init,
+                                  int W, int H, int num_iters, float *cost_out, float *disp, void *stream);
 
 /* =====================================================================================
  * Window matchers                     replace SAD/Sad.h, NCC/NCC.h, ASW/ASW.h

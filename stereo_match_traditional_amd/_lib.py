@@ -27,6 +27,15 @@ class CrossArmParams(C.Structure):
                 ("max_length", C.c_int), ("chain_tau", C.c_int), ("quirks", C.c_uint)]
 
 
+class ADCensusOption(C.Structure):
+    """struct ADCensusOption (CBLSM/adcensus_types.h:45-75)."""
+    _fields_ = [("min_disparity", C.c_int32), ("max_disparity", C.c_int32), ("lambda_ad", C.c_int32),
+                ("lambda_census", C.c_int32), ("cross_L1", C.c_int32), ("cross_L2", C.c_int32), ("cross_t1", C.c_int32),
+                ("cross_t2", C.c_int32), ("so_p1", C.c_float), ("so_p2", C.c_float), ("so_tso", C.c_int32),
+                ("irv_ts", C.c_int32), ("irv_th", C.c_float), ("lrcheck_thres", C.c_float), ("do_lr_check", C.c_int32),
+                ("do_filling", C.c_int32), ("do_discontinuity_adjustment", C.c_int32)]
+
+
 _lib = None
 
 

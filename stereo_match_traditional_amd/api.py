@@ -15,7 +15,7 @@ __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "choose
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
-           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite"]
+           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate"]
 
 
 def current_stream_ptr():
@@ -299,6 +299,10 @@ class CrossArmAggregation:
         5 = no group skip, 3 = 1x8,
         0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
+
+    def set_arm_walk(self, on=True):
+        """Arms by the neighbour-by-neighbour kernels (independent formulation) instead of the bit-mask ones."""
+        check(lib().smt_crossarm_set_arm_walk(self._h, int(on)), "smt_crossarm_set_arm_walk")
 
     def set_sweep(self, sweep):
         check(lib().smt_crossarm_set_sweep(self._h, int(sweep)), "smt_crossarm_set_sweep")
@@ -720,3 +724,30 @@ def imwrite(path, img):
     H, W = a.shape[:2]
     ch = 1 if a.ndim == 2 else a.shape[2]
     check(lib().smt_image_write(str(path).encode(), a.ctypes.data_as(C.c_void_p), H, W, ch), "smt_image_write")
+
+
+# ======================================================================================
+# ADCensusOption (CBLSM/adcensus_types.h:45-75) and the caller shape of CBLSM.cpp:138-143
+# ======================================================================================
+def ADCensusOption(**overrides):
+    """Default-constructed ADCensusOption (adcensus_types.h:69-75) with fields overridden by keyword."""
+    o = _lib.ADCensusOption()
+    lib().smt_adcensus_option_default(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def adcensus_option_aggregate(option, bytes_left, dispVolum, num_iters=4, want_disp=True):
+    """CBLSM.cpp:138-143 + :152: CrossAggregator driven by an ADCensusOption -> (cost, disp)."""
+    H, W, _ = bytes_left.shape
+    D = option.max_disparity - option.min_disparity
+    _dev(bytes_left, torch.uint8, (H, W, 3), "bytes_left")
+    _dev(dispVolum, torch.float32, (H, W, D), "dispVolum")
+    cost = torch.empty((H, W, D), dtype=torch.float32, device=dispVolum.device)
+    disp = torch.empty((H, W), dtype=torch.float32, device=dispVolum.device) if want_disp else None
+    check(lib().smt_adcensus_option_aggregate(C.byref(option), _ptr(bytes_left), _ptr(dispVolum), W, H, int(num_iters),
+                                              _ptr(cost), _ptr(disp), current_stream_ptr()), "smt_adcensus_option_aggregate")
+    return cost, disp

@@ -16,7 +16,8 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(HERE, "..", "include", "smt.h")]
+    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(HERE, "host", "*")) + \
+        [os.path.join(HERE, "..", "include", "smt.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

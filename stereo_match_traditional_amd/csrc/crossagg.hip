@@ -232,3 +232,35 @@ SMT_API int smt_crossagg_arms(smt_crossagg *h, uint8_t **arms)
     *arms = h->arms;
     return SMT_OK;
 }
+
+// ---- ADCensusOption (CBLSM/adcensus_types.h:45-75) and the one caller shape the reference holds ------------
+SMT_API void smt_adcensus_option_default(smt_adcensus_option *o)
+{
+    if (!o) return;
+    o->min_disparity = 0; o->max_disparity = 64;          // adcensus_types.h:69
+    o->lambda_ad = 10; o->lambda_census = 30;
+    o->cross_L1 = 34; o->cross_L2 = 17; o->cross_t1 = 20; o->cross_t2 = 6;
+    o->so_p1 = 1.0f; o->so_p2 = 3.0f; o->so_tso = 15;
+    o->irv_ts = 20; o->irv_th = 0.4f;
+    o->lrcheck_thres = 1.0f;
+    o->do_lr_check = 1; o->do_filling = 1; o->do_discontinuity_adjustment = 0;
+}
+
+SMT_API int smt_adcensus_option_aggregate(const smt_adcensus_option *o, const uint8_t *bytes_left, const float *cost_init,
+                                          int W, int H, int num_iters, float *cost_out, float *disp, void *stream)
+{
+    if (!o || !bytes_left || !cost_init || !cost_out || num_iters < 0) return SMT_ERR_ARG;
+    const int D = o->max_disparity - o->min_disparity;
+    smt_crossagg *h = nullptr;
+    int rc = smt_crossagg_create(W, H, D, &h);                                           // Initialize(col, row, 0, dispRange), CBLSM.cpp:139
+    if (rc != SMT_OK) return rc;
+    rc = smt_crossagg_set_stream(h, stream);
+    if (rc == SMT_OK) rc = smt_crossagg_set_params(h, o->cross_L1, o->cross_L2, o->cross_t1, o->cross_t2);   // :141
+    if (rc == SMT_OK) rc = smt_crossagg_aggregate(h, bytes_left, cost_init, num_iters);  // SetData + Aggregate, :140, :142
+    if (rc == SMT_OK && hipMemcpyAsync(cost_out, h->cur, (size_t)W * H * D * 4, hipMemcpyDeviceToDevice, smt_stream(stream)) != hipSuccess)
+        rc = SMT_ERR_HIP;                                                                // get_cost_ptr, :143
+    if (rc == SMT_OK && disp) rc = smt_wta(cost_out, H, W, D, disp, stream);             // ComputeDispOringin, :152
+    if (hipStreamSynchronize(smt_stream(stream)) != hipSuccess && rc == SMT_OK) rc = SMT_ERR_HIP;
+    smt_crossagg_destroy(h);
+    return rc;
+}

@@ -130,6 +130,107 @@ __global__ void __launch_bounds__(NT) k_arms(const uint8_t *__restrict__ img, Ar
     out[(size_t)i * colR + j] = saved;
 }
 
+// ---- arms without the dependent-load chain ---------------------------------------------------------
+// k_arm_flip / k_arms above walk an arm neighbour by neighbour and stop at the first failure: up to 34
+// DEPENDENT byte loads per thread (0.28 ms per 1080p image for the two kernels).  For max(max_length,
+// sec_length) <= 63 the walk is replaced by bit masks: every neighbour 1..K of the pixel is loaded
+// unconditionally (independent loads), bit k-1 of m_hi / m_lo says |I(p) - I(p + k*delta)| > tau / tau_low,
+// the image border is one more stop bit, and the reference's result for either threshold state is a
+// count-trailing-zeros away (A.4 of SURVEY.md):
+//   phase A, k <= sec, threshold tA (tau, or tau_low once lowered): first stop bit f -> saved = f
+//            (forced to 1 when the stop is a difference, saved < 1 and the pixel is 2 or more from that border);
+//   phase B, sec < k <= K = max(maxlen, sec), threshold tau_low: first stop bit, else saved = K.
+// A pixel flips the sticky threshold iff phase A with tau has no stop bit (it enters iteration sec+1).
+// k_arm_cand writes both candidates (threshold still tau / already tau_low) and finds the first flipping
+// pixel per direction; k_arm_pick selects with the same rule as k_arms.  Same index spaces as above
+// (direction 1 with the stride bug runs over j < H and stores with stride H).
+template <bool GRAY>
+__global__ void __launch_bounds__(NT) k_arm_cand(const uint8_t *__restrict__ img, ArmCfg c, int *flip, int dir0,
+                                                 const int *__restrict__ tau_state, uint16_t *__restrict__ cand)
+{
+    const int dir = dir0 + blockIdx.y;
+    const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    const bool live = idx < c.H * colR;
+    const int i = live ? idx / colR : 0, j = live ? idx - i * colR : 0;
+    int kmax, step;
+    bool far;
+    switch (dir) {
+    case 0: kmax = j; step = -1; far = (j - 1 >= 1); break;
+    case 1: kmax = colR - 1 - j; step = 1; far = (j + 1 < colR - 1); break;
+    case 2: kmax = i; step = -c.W; far = (i - 1 >= 1); break;
+    default: kmax = c.H - 1 - i; step = c.W; far = (i + 1 < c.H - 1); break;
+    }
+    const int K = max(c.maxlen, c.sec);
+    const int nk = min(kmax, K);
+    const int base = i * c.W + j;
+    // masks are built far-to-near, m = 2m + flag: one compare + one add-with-carry per threshold and
+    // neighbour, as two 32-bit halves (bits 0..31 for k = 1..32, the upper word for k = 33..63).  A lane
+    // whose arm cannot reach neighbour k (border) re-reads its own pixel instead: difference 0, no flag
+    // (thresholds are >= 0 on this path).
+    unsigned h_hi = 0, h_lo = 0, l_hi = 0, l_lo = 0;
+    const int self = GRAY ? (int)img[base] : 0;
+    auto sweep = [&](int kfrom, int kto, unsigned &m_hi, unsigned &m_lo) {     // k = kfrom down to kto
+        constexpr int U = 8;                                                   // neighbours loaded per batch
+        for (int k0 = kfrom; k0 >= kto; k0 -= U) {
+            int d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = k0 - u;
+                const unsigned nb = (k >= kto && k <= nk) ? (unsigned)(base + k * step) : (unsigned)base;
+                d[u] = GRAY ? (int)__builtin_amdgcn_sad_u8((unsigned)self, (unsigned)img[nb], 0u) : pix_diff(img, c.ch, base, (int)nb);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (k0 - u >= kto) {                                           // wave-uniform
+                    asm("v_cmp_lt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m_hi) : "s"(c.tau), "v"(d[u]) : "vcc");
+                    asm("v_cmp_lt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m_lo) : "s"(c.tau_low), "v"(d[u]) : "vcc");
+                }
+        }
+    };
+    if (K > 32) sweep(K, 33, h_hi, h_lo);
+    sweep(min(K, 32), 1, l_hi, l_lo);
+    const unsigned long long mhi = ((unsigned long long)h_hi << 32) | l_hi, mlo = ((unsigned long long)h_lo << 32) | l_lo;
+    const unsigned long long oob = kmax < 64 ? 1ull << kmax : 0ull;      // neighbour kmax+1 is outside
+    const unsigned long long lowmask = c.sec >= 64 ? ~0ull : (1ull << c.sec) - 1;
+    const unsigned long long allmask = K >= 64 ? ~0ull : (1ull << K) - 1;
+    auto walk = [&](unsigned long long mA) {
+        unsigned long long st = (mA | oob) & lowmask;
+        if (!st) st = (mlo | oob) & allmask & ~lowmask;
+        if (!st) return K;
+        int saved = __builtin_ctzll(st);
+        if (saved != kmax && saved < 1 && far) saved = 1;                // stopped by a difference, not by the border
+        return saved;
+    };
+    if (live) cand[(size_t)dir * c.H * c.W + idx] = (uint16_t)(walk(mhi) | (walk(mlo) << 8));
+    // first pixel (row-major in this direction's index space) that passes sec neighbours under tau
+    const bool qual = live && ((mhi | oob) & lowmask) == 0;
+    if (*tau_state != c.tau) return;
+    const unsigned long long b = __ballot(qual);
+    if (b && (threadIdx.x & 63) == 0) {
+        const int first = idx + __builtin_ctzll(b);
+        if (first < *(volatile int *)&flip[dir]) atomicMin(&flip[dir], first);
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_arm_pick(ArmCfg c, const int *__restrict__ flip, const uint16_t *__restrict__ cand,
+                                                 int *armL, int *armR, int *armT, int *armB, int dir0, int prev_flips,
+                                                 const int *__restrict__ tau_state)
+{
+    const int dir = dir0 + blockIdx.y;
+    const int colR = (dir == 1 && !c.fix_right) ? c.H : c.W;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= c.H * colR) return;
+    int tau_in = *tau_state;
+    if (c.chain && prev_flips)
+        for (int e = 0; e < dir; e++)
+            if (flip[e] != INT_MAX) tau_in = c.tau_low;
+    const unsigned v = cand[(size_t)dir * c.H * c.W + idx];
+    const bool hi = (tau_in == c.tau) && idx <= flip[dir];
+    int *out = dir == 0 ? armL : dir == 1 ? armR : dir == 2 ? armT : armB;
+    out[idx] = hi ? (int)(v & 255u) : (int)(v >> 8);
+}
+
 // after the direction(s) dir0 .. dir0+ndir-1: a member threshold (chain) that flipped stays lowered
 __global__ void k_tau_update(const int *__restrict__ flip, int dir0, int ndir, int chain, int tau_low, int *tau_state)
 {
@@ -958,6 +1059,8 @@ struct smt_crossarm {
     int strip_w8;        // the same for variant 3 (8 pixels per wave)
     int sweep;           // 0: strips interleaved over XCDs, 1: each XCD owns a band of rows (variants 3-5)
     float *member;       // 256 x 8 membership flags for variant 3
+    uint16_t *cand;      // [4][H][W] arm candidates {threshold still tau, already tau_low} (mask-based arm kernels)
+    bool arm_walk;       // test hook: use the neighbour-by-neighbour kernels even when the masks apply
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -985,6 +1088,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     for (int k = 0; k < 4 && rc == SMT_OK; k++) rc = smt_malloc((void **)&h->arm[k], (size_t)H * W * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->flip, 8 * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->member, MEMBER_TAB_FLOATS * 4);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->cand, (size_t)H * W * 4 * sizeof(uint16_t));
     if (rc != SMT_OK) { smt_crossarm_destroy(h); return rc; }
     if (hipMemset(h->flip, 0, 32) != hipSuccess) { smt_crossarm_destroy(h); return SMT_ERR_HIP; }
     // Initialize (CrossArm.cpp:6-18): `_tao = tao` and four value-initialised (zero) maps
@@ -1016,6 +1120,7 @@ SMT_API int smt_crossarm_destroy(smt_crossarm *h)
     for (int k = 0; k < 4; k++) (void)hipFree(h->arm[k]);
     (void)hipFree(h->flip);
     (void)hipFree(h->member);
+    (void)hipFree(h->cand);
     delete h;
     return SMT_OK;
 }
@@ -1029,6 +1134,22 @@ SMT_API int smt_crossarm_set_stream(smt_crossarm *h, void *s)
 }
 
 static const int kFlipInit[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+
+// flip search + arm lengths of the directions dir0 .. dir0 + grid.y - 1
+static void launch_arms(smt_crossarm *h, const uint8_t *img, const ArmCfg &c, dim3 grid, int dir0, int prev_flips)
+{
+    const bool masks = !h->arm_walk && c.sec <= 63 && c.maxlen <= 63 && c.tau >= 0 && c.tau_low >= 0;
+    if (masks) {
+        if (c.ch == 1) hipLaunchKernelGGL(k_arm_cand<true>, grid, dim3(NT), 0, h->stream, img, c, h->flip, dir0, h->flip + 5, h->cand);
+        else hipLaunchKernelGGL(k_arm_cand<false>, grid, dim3(NT), 0, h->stream, img, c, h->flip, dir0, h->flip + 5, h->cand);
+        hipLaunchKernelGGL(k_arm_pick, grid, dim3(NT), 0, h->stream, c, h->flip, h->cand, h->arm[0], h->arm[1],
+                           h->arm[2], h->arm[3], dir0, prev_flips, h->flip + 5);
+    } else {
+        hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip, dir0, h->flip + 5);
+        hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
+                           h->arm[2], h->arm[3], dir0, prev_flips, h->flip + 5);
+    }
+}
 
 SMT_API int smt_crossarm_reset(smt_crossarm *h)
 {
@@ -1059,9 +1180,7 @@ SMT_API int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels)
     if (rc != SMT_OK) return rc;
     SMT_HIP(hipMemcpyAsync(h->flip, kFlipInit, 16, hipMemcpyHostToDevice, h->stream));
     dim3 grid((unsigned)((N + NT - 1) / NT), 4);
-    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip, 0, h->flip + 5);
-    hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
-                       h->arm[2], h->arm[3], 0, 1, h->flip + 5);
+    launch_arms(h, img, c, grid, 0, 1);
     hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(1), 0, h->stream, h->flip, 0, 4, h->P.chain_tau, h->P.tau_low,
                        h->flip + 5);
     SMT_LAUNCH_CHECK();
@@ -1080,9 +1199,7 @@ SMT_API int smt_crossarm_arm_dir(smt_crossarm *h, const uint8_t *img, int channe
     const size_t N = (size_t)h->H * h->W;
     SMT_HIP(hipMemcpyAsync(h->flip + dir, kFlipInit, 4, hipMemcpyHostToDevice, h->stream));
     dim3 grid((unsigned)((N + NT - 1) / NT), 1);
-    hipLaunchKernelGGL(k_arm_flip, grid, dim3(NT), 0, h->stream, img, c, h->flip, dir, h->flip + 5);
-    hipLaunchKernelGGL(k_arms, grid, dim3(NT), 0, h->stream, img, c, h->flip, h->arm[0], h->arm[1],
-                       h->arm[2], h->arm[3], dir, 0, h->flip + 5);
+    launch_arms(h, img, c, grid, dir, 0);
     hipLaunchKernelGGL(k_tau_update, dim3(1), dim3(1), 0, h->stream, h->flip, dir, 1, h->P.chain_tau, h->P.tau_low,
                        h->flip + 5);
     SMT_LAUNCH_CHECK();
@@ -1252,6 +1369,13 @@ SMT_API int smt_crossarm_set_strip_width(smt_crossarm *h, int w)
     if (!h || w < 4 || (w & 3)) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->strip_w = w; h->strip_w8 = w;
+    return SMT_OK;
+}
+
+SMT_API int smt_crossarm_set_arm_walk(smt_crossarm *h, int on)
+{
+    if (!h) return SMT_ERR_ARG;
+    h->arm_walk = on != 0;
     return SMT_OK;
 }
 

@@ -637,3 +637,24 @@ def test_cblsm_cost_aggregation_new(smt, O, H, W, D, win, seed):
     got = smt.costAggregationNew(T(Lp), T(Rp), None, *[T(v) for v in vols], D, H, W, win)
     assert np.array_equal(bits(got.cpu().numpy()), bits(ref))
     assert np.isfinite(ref).all() and ref.max() > 0
+
+
+@pytest.mark.parametrize("kind,seed", [("synth", 3), ("smooth", 5), ("noise", 4), ("flat", 0)])
+@pytest.mark.parametrize("sec,maxlen", [(17, 34), (5, 63), (0, 3), (20, 10), (40, 100)])
+def test_arm_kernels_masks_vs_walk_vs_oracle(smt, O, kind, seed, sec, maxlen):
+    """The bit-mask arm kernels (default for sec, maxlen <= 63), the neighbour-by-neighbour kernels
+    (set_arm_walk; the only path beyond 63) and the oracle's sequential walk agree for ordinary and odd
+    (sec = 0, maxlen < sec, long) parameters, gray and 3-channel, both threshold styles."""
+    H, W = 70, 150
+    img = _img(H, W, kind, seed, O)
+    img3 = O.synth_bgr(img, seed + 1)
+    for image in (img, img3):
+        for style, tau, chain, bug in (("adcensus", 30, True, True), ("cblsm", 25, False, False)):
+            ref = O.arms_all(image, tau, 6, sec, maxlen, chain=chain, right_row_bug=bug)
+            for walk in (False, True):
+                ca = smt.CrossArmAggregation().Initialize(H, W, tau, 16, DEV, style=style, sec_length=sec, max_length=maxlen)
+                ca.set_arm_walk(walk)
+                ca.ComputeArmLengths(T(image))
+                for g, r in zip(ca.arm_maps(), ref):
+                    assert np.array_equal(g.cpu().numpy(), r), (style, walk, image.ndim)
+                ca.close()

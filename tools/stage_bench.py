@@ -43,6 +43,10 @@ def pipeline(H, W, D, seed, noise, reps):
     caL = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
     caR = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
     res["arms_ms"] = timed(lambda: (caL.ComputeArmLengths(Lu), caR.ComputeArmLengths(Ru)), reps)
+    caL.set_arm_walk(True)
+    res["arms_walk_one_image_ms"] = timed(lambda: caL.ComputeArmLengths(Lu), reps)
+    caL.set_arm_walk(False)
+    res["arms_masks_one_image_ms"] = timed(lambda: caL.ComputeArmLengths(Lu), reps)
     aL, aR, aT, aB = [a.float() for a in caL.arm_maps()]
     area = (aL + aR + 1) * (aT + aB + 1)
     res["mean_arm"] = float((aL + aR + aT + aB).mean() / 4)
@@ -51,10 +55,10 @@ def pipeline(H, W, D, seed, noise, reps):
     aggR = torch.empty((H, W, D), device=DEV)
     rL, rR, rT, rB = [a.float() for a in caR.arm_maps()]
     res["mean_rect_area_right"] = float(((rL + rR + 1) * (rT + rB + 1)).mean())
-    for v in (0, 1, 2, 3, 5):
+    for v in (0, 1, 2, 3, 4, 5):
         caL.set_variant(v)
         res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
-    caL.set_variant(4)
+    caL.set_variant(6)
     for sw in (8, 32, 64):
         caL.set_strip_width(sw)
         res[f"aggregate_L_strip{sw}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
@@ -92,6 +96,18 @@ def matchers(reps):
     sp, cm = smt.asw_masks(ws, 50.0, 30.0, DEV)
     res["asw_cfg4_left_ms"] = timed(lambda: smt.AdaptiveSupportWeight(Lp, Rp, ws, D, sp, cm, 40), 1)
     res["asw_cfg4_TFLOPs_f64"] = 8 * 35 * 35 * H * W * D / res["asw_cfg4_left_ms"] / 1e9
+    # CrossAggregator (a18) at 720p D=128: arms + 4 iterations x 2 passes
+    H, W, D = 720, 1280, 128
+    L, R = synth.synth_pair(H, W, D, 2)
+    bgr = torch.from_numpy(np.repeat(L[..., None], 3, axis=2).copy()).to(DEV)
+    cost = torch.rand((H, W, D), device=DEV)
+    ca = smt.CrossAggregator()
+    ca.Initialize(W, H, 0, D, DEV)
+    ca.SetData(bgr, bgr, cost)
+    ca.SetParams(34, 17, 20, 6)
+    res["crossagg_720p_d128_4iters_ms"] = timed(lambda: ca.Aggregate(4), 3)
+    res["crossagg_alg_GBs(8B x 8 passes)"] = 64 * H * W * D / res["crossagg_720p_d128_4iters_ms"] / 1e6
+    ca.close()
     # NCC 21x21 450x375 D=64
     H, W, D = 375, 450, 64
     L, R = synth.synth_pair(H, W, D, 1)
