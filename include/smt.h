@@ -239,10 +239,12 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
                                              plane since the previous status call / reset / arms */
-/* Test / tuning hook: which aggregation kernel runs.  6 = 2x8 pixels per wave, every tap of the
+/* Test / tuning hook: which aggregation kernel runs.  7 = 2x8 pixels per wave, every tap of the
  * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
- * a member skipped, flag rows fetched one tap ahead (default), 4 = the same with the flags fetched per
- * live group, 5 = 4 without the skip, 3 = 1x8 pixels without the skip,
+ * a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
+ * workgroup (8 x 8 pixels) walking their common bounding box in lock-step, one s_barrier per 64 positions
+ * (default; also resets the strip width to 8), 6 = the same free-running (strip width 16), 4 = 6 with the
+ * flags fetched per live group and pixel-by-pixel classification, 5 = 4 without the skip, 3 = 1x8 pixels without the skip,
  * 0 = four adjacent pixels per wave (mask switch), 1 = plain one-pixel-per-wave walk,
  * 2 = pipelined one-pixel-per-wave walk.  All produce identical bits. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);

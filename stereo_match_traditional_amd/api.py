@@ -295,7 +295,8 @@ class CrossArmAggregation:
         wta(AggredCostVolume, disp)
 
     def set_variant(self, variant):
-        """6 = 2x8 pixels per wave sharing union taps, flags prefetched (default), 4 = flags per live group,
+        """7 = 2x8 pixels per wave sharing union taps, flags prefetched, waves of a workgroup in lock-step
+        (default), 6 = the same free-running, 4 = flags per live group,
         5 = no group skip, 3 = 1x8,
         0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")

@@ -648,10 +648,18 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
     constexpr int QC = 8, NPIX = QC * QR;
     constexpr int G = (QR == 1) ? 8 : 4;                 // union taps loaded per group
     constexpr int BIAS = 16384;
+    // SKIP == 3 ("lock-step"): SKIP == 2 plus one s_barrier per batch of 64 box positions, with all four waves
+    // of the workgroup enumerating the positions of their COMMON bounding box.  The waves own neighbouring
+    // tiles whose unions overlap; an XCD's 4 MB L2 is refilled every ~5 us at this kernel's fetch rate, so a
+    // line fetched for one tile is gone before a free-running neighbour asks for it (TCC: ~10 fabric fetches
+    // per input line).  Walking the same columns at the same time turns those re-fetches into L2 hits.
+    constexpr bool SYNC = (SKIP == 3);
+    constexpr bool PREF = (SKIP >= 2);                   // flag rows fetched one tap ahead + per-axis tables
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = H * W;
     int p0, ncol, nrow;
+    int ooff = 0, ioff = 0;                              // this wave's tile origin inside the workgroup's block
     {
         // XCD x = blockIdx%8 owns the column strips x, x+8, ... of width SW; a workgroup covers
         // wx*8 columns by wy*QR rows (wx*wy = 4 waves), so narrow strips stack the waves vertically.
@@ -677,10 +685,20 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
             row = ((xcd * nbx + g / gpr) * wy + wv / wx) * QR;
             col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
         }
-        if (row >= H || col >= W) return;
+        if (SYNC) {
+            const int roff = (wv / wx) * QR, coff = (wv % wx) * QC;
+            ooff = (ORDER == 0) ? coff : roff;
+            ioff = (ORDER == 0) ? roff : coff;
+        }
+        if (row >= H || col >= W) {
+            if (!SYNC) return;
+            row = 0; col = 0;                              // stays for the barriers; owns no pixel
+            ncol = 0; nrow = 0;
+        } else {
+            ncol = min(QC, W - col);
+            nrow = min(QR, H - row);
+        }
         p0 = row * W + col;
-        ncol = min(QC, W - col);
-        nrow = min(QR, H - row);
     }
     const int so = (ORDER == 0) ? 1 : W, si = (ORDER == 0) ? W : 1;
     // lane q: rectangle of pixel q as outer [oa, ob] x inner [ia, ib]; empty for pixels off the image
@@ -788,20 +806,62 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
         }
     };
 
-    if (!ub) {
-        const int nIb = imax - imin + 1;
-        const int total = (omax - omin + 1) * nIb;
+    // box whose positions are enumerated: the wave's own bounding box, or (SYNC) the common one of the four
+    // waves in workgroup coordinates (wave-relative position = workgroup-relative - (ooff, ioff))
+    int bo0 = omin, bo1 = omax, bi0 = imin, bi1 = imax;
+    if (SYNC) {
+        __shared__ int s_bb[NT / 64][4];
+        if (lane == 0) {
+            const bool any = omax >= omin;
+            s_bb[wv][0] = any ? omin + ooff : INT_MAX; s_bb[wv][1] = any ? omax + ooff : INT_MIN;
+            s_bb[wv][2] = any ? imin + ioff : INT_MAX; s_bb[wv][3] = any ? imax + ioff : INT_MIN;
+        }
+        __syncthreads();
+        bo0 = INT_MAX; bo1 = INT_MIN; bi0 = INT_MAX; bi1 = INT_MIN;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+            bo0 = min(bo0, s_bb[w][0]); bo1 = max(bo1, s_bb[w][1]);
+            bi0 = min(bi0, s_bb[w][2]); bi1 = max(bi1, s_bb[w][3]);
+        }
+        if (bo1 >= bo0) { bo0 -= ooff; bo1 -= ooff; bi0 -= ioff; bi1 -= ioff; }   // back to this wave's coordinates
+        if (ub && lane == 0) atomicOr(ub_flag, 1);
+    }
+    if (SYNC || !ub) {
+        const int nIb = (bo1 >= bo0) ? bi1 - bi0 + 1 : 1;
+        const int total = (bo1 >= bo0) ? (bo1 - bo0 + 1) * nIb : 0;
         const float rI = 1.0f / (float)nIb;
+        // per-axis membership tables (SKIP == 2 only; bounding boxes wider or taller than 64 -- arms of 28 and
+        // more on both sides -- classify pixel by pixel as before): lane l holds, as one bit per pixel of the
+        // tile, which pixels' outer ranges contain omin + l (tab_o) and which inner ranges contain imin + l (tab_i)
+        const bool axis_tables = PREF && (omax >= omin) && (omax - omin + 1 <= 64) && (imax - imin + 1 <= 64);
+        unsigned tab_o = 0, tab_i = 0;
+        if (axis_tables) {
+            const unsigned ob16 = (unsigned)(lane + omin + BIAS), tb16 = (unsigned)(lane + imin + BIAS);
+#pragma unroll
+            for (int q = 0; q < NPIX; q++) {
+                const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q);
+                const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
+                tab_o |= (unsigned)(ob16 >= (bo & 0xffffu) && ob16 <= (bo >> 16)) << q;
+                tab_i |= (unsigned)(tb16 >= (bi & 0xffffu) && tb16 <= (bi >> 16)) << q;
+            }
+        }
         for (int n0 = 0; n0 < total; n0 += 64) {
             const int n = n0 + lane;
             int o = (int)((float)n * rI);
             int t = n - o * nIb;
             if (t < 0) { o--; t += nIb; }
             if (t >= nIb) { o++; t -= nIb; }
-            o += omin; t += imin;
-            asm volatile("" : "+v"(pk_o), "+v"(pk_i));   // keep the broadcasts below inside the loop
+            o += bo0; t += bi0;
             unsigned mask = 0;
-            {
+            if (axis_tables) {
+                // membership of position (o, t) = (pixels whose outer range holds o) & (pixels whose inner range
+                // holds t): two per-axis bit tables built once per tile, fetched from the lane that owns the index
+                const unsigned mo = (unsigned)__builtin_amdgcn_ds_bpermute((o - omin) << 2, (int)tab_o);
+                const unsigned mi = (unsigned)__builtin_amdgcn_ds_bpermute((t - imin) << 2, (int)tab_i);
+                const bool own = !SYNC || (o >= omin && o <= omax && t >= imin && t <= imax);   // inside this wave's own box
+                mask = (n < total && own) ? (mo & mi) : 0u;
+            } else {
+                asm volatile("" : "+v"(pk_o), "+v"(pk_i));   // keep the broadcasts below inside the loop
                 const unsigned ob16 = (unsigned)(o + BIAS), tb16 = (unsigned)(t + BIAS);
 #pragma unroll
                 for (int q = 0; q < NPIX; q++) {
@@ -812,6 +872,7 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
                 }
                 if (n >= total) mask = 0;
             }
+            if (SYNC && ub) mask = 0;                    // reference-undefined tile: every pixel goes to the plain walk below
             const unsigned offs = (unsigned)(p0 + o * so + t * si) * (unsigned)(D * 4);
             unsigned long long live = __ballot(mask != 0);
             // groups of union taps: indices, then all loads, then the in-order adds.  A short last
@@ -837,7 +898,7 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
-                if (SKIP == 2) {
+                if (PREF) {
                     f8 F[2][QR];
                     load_flags(m[0], F[0]);
 #pragma unroll
@@ -857,6 +918,7 @@ __global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict_
             for (; cnt >= G; cnt -= G) group(std::integral_constant<int, G>{}, std::false_type{});
             if (G == 8 && cnt > 4) group(std::integral_constant<int, G>{}, std::true_type{});
             else if (cnt > 0) group(std::integral_constant<int, 4>{}, std::true_type{});
+            if (SYNC) __builtin_amdgcn_s_barrier();      // time alignment only: nothing is exchanged through memory
         }
     } else if (lane == 0) atomicOr(ub_flag, 1);
 
@@ -1081,7 +1143,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
-    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 16; h->variant = 6;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 7;
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
@@ -1351,6 +1413,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 4) { if (order == 0) launch_agg_multi<0, 2, 1>(h, vin, vout, disp); else launch_agg_multi<1, 2, 1>(h, vin, vout, disp); }
     else if (variant == 5) { if (order == 0) launch_agg_multi<0, 2, 0>(h, vin, vout, disp); else launch_agg_multi<1, 2, 0>(h, vin, vout, disp); }
     else if (variant == 6) { if (order == 0) launch_agg_multi<0, 2, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 2>(h, vin, vout, disp); }
+    else if (variant == 7) { if (order == 0) launch_agg_multi<0, 2, 3>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1358,9 +1421,12 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 6) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 7) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->variant = variant;
+    // the lock-step kernel wants its four waves stacked vertically (8 columns x 8 rows per workgroup: the
+    // waves then walk the same columns); the free-running ones measure best with 16-column strips
+    h->strip_w8 = variant == 7 ? 8 : 16;
     return SMT_OK;
 }
 
