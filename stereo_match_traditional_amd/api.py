@@ -14,7 +14,7 @@ from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "costAggregationNew", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
-           "AdaptiveSupportWeight", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
+           "AdaptiveSupportWeight", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
            "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate"]
 
 
@@ -639,6 +639,11 @@ def AdaptiveSupportWeight(leftGray, rightGray, winSize, dispRange, space, color,
     check(lib().smt_asw(_ptr(leftGray), _ptr(rightGray), H, W, dispRange, winSize, _ptr(space), _ptr(color), int(T),
                         view, _ptr(disp), _ptr(cost), current_stream_ptr()), "smt_asw")
     return (disp, cost) if want_cost else disp
+
+
+def asw_set_impl(impl):
+    """3 = table-driven ASW kernels (default), 1 = first formulation (test hook)."""
+    check(lib().smt_asw_set_impl(int(impl)), "smt_asw_set_impl")
 
 
 def asw_CrossCheckDiaparity(leftdisp, rightdisp):

@@ -308,7 +308,179 @@ __global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, con
     }
 }
 
+// ---- ASW, second formulation (default) ---------------------------------------------------------------
+// k_asw above is VALU-issue bound (rocprofv3: 98.8 % of the SIMD cycles issue a vector instruction, 11.4 per
+// tap and hypothesis slot).  Two of its per-tap costs do not depend on the hypothesis the lane owns:
+//   * the anchor weight w0(q)*space(q)^2 and the anchor byte are wave-uniform, yet reach the FMAs through
+//     three v_readlane per tap.  k_asw_anchor writes them once per pixel to a table in HBM
+//     ([pixel][tap] float64, 5 GB at 960x540 / 35x35, a fraction of a millisecond to write) and a
+//     dword-per-pixel copy of the anchor image; the main kernel reads both through the SCALAR cache
+//     (uniform addresses, s_load), which costs no vector issue slot at all;
+//   * the other image's weight color[|B(q) - B(centre)|] depends only on the window position in the other
+//     image, xs = j -+ d, not on (j, d) separately: the 16 pixels of a workgroup x D hypotheses touch only
+//     16 + D - 1 window positions per row.  Per window row the workgroup builds that table once in LDS
+//     (T[column][xs], float64) and every lane reads its entry with one linear, conflict-free ds_read_b64 --
+//     no |difference|, no table-address arithmetic, no random LDS access in the tap loop.
+// What is left per tap and slot: byte extract, |pa - pb|, min T, int -> f64, one multiply, two FMAs.
+// Arithmetic and summation order are those of k_asw (and the results identical bit for bit): the table
+// holds the same float64 products w0*space^2, and sw / sv accumulate the taps in the same order.
+constexpr int A3P = 16;                                   // pixels (waves) per workgroup
+
+__global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ Ap, int H, int W, int wins,
+                                                    const double *__restrict__ space, const double *__restrict__ color,
+                                                    double *__restrict__ w0, unsigned *__restrict__ a32)
+{
+    // one wave per pixel, 4 pixels per workgroup; the wave walks the pixel's side*side taps 64 at a time, so its
+    // stores are whole 512-byte pieces of the table
+    const int side = 2 * wins + 1, Wp = W + 2 * wins, Hp = H + 2 * wins;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // one dword per anchor pixel (scalar / uniform loads want 4-byte elements)
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Hp * Wp; k += (size_t)gridDim.x * 256) a32[k] = Ap[k];
+    const size_t p = (size_t)blockIdx.x * 4 + wv;
+    if (p >= (size_t)H * W) return;
+    const int io = (int)(p / W), jo = (int)(p % W);
+    const uint8_t *A = Ap + (size_t)io * Wp + jo;
+    const int ca = A[wins * Wp + wins];
+    const int ntap = side * side;
+    const float rs = 1.0f / (float)side;
+    double *out = w0 + p * ntap;
+    for (int t = lane; t < ntap; t += 64) {
+        int r = (int)((float)t * rs);                      // t / side, corrected below
+        int c = t - r * side;
+        if (c < 0) { r--; c += side; }
+        if (c >= side) { r++; c -= side; }
+        const int pa = A[r * Wp + c];
+        const double sp = space[t];
+        out[t] = color[abs(pa - ca)] * (sp * sp);          // the two products of k_asw, same order
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                                   int W, int D, int wins, const double *__restrict__ color,
+                                                   const double *__restrict__ w0, const unsigned *__restrict__ a32, int T,
+                                                   int view, float *__restrict__ disp, float *__restrict__ cost_out)
+{
+    constexpr int NXP = A3P + 64 * K;                      // window positions of the other image per row (padded)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int side = 2 * wins + 1, Wp = W + 2 * wins;
+    double *s_T = (double *)smem;                          // [side][NXP]
+    double *s_color = s_T + (size_t)side * NXP;            // [256]
+    for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int io = blockIdx.y, jo0 = blockIdx.x * A3P;
+    const int jo = jo0 + wv;
+    const bool live = jo < W;                              // waves past the row end still help to build the tables
+    const int jc = live ? jo : W - 1;
+    // the other image and the first window position the workgroup can touch:
+    //   view 0: xs = jo - dd in [jo0 - (D-1), jo0 + 15];   view 1: xs = jo + dd in [jo0, jo0 + 15 + D-1]
+    const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
+    const int xbase = (view == 0) ? jo0 - (64 * K - 1) : jo0;
+    const int dmax = (view == 0) ? jc : (W - wins - 2 - jc);   // last in-range disparity (ASW.h:348 / :401)
+    const double *wrow = w0 + ((size_t)io * W + jc) * side * side;
+    const unsigned *arow = a32 + (size_t)io * Wp + jc;
+
+    double sw[K], sv[K];
+    unsigned xo[K];                                        // window position of slot k in the other image's row
+    const double *tk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int d = lane + 64 * k;
+        const int dd = d < dmax ? d : (dmax < 0 ? 0 : dmax);   // d >= D lanes compute a harmless duplicate
+        const int xs = (view == 0) ? jc - dd : jc + dd;
+        xo[k] = (unsigned)xs;
+        tk[k] = s_T + (xs - xbase);
+        sw[k] = 0.0; sv[k] = 0.0;
+    }
+    const int nfull = side >> 2, ctail = side - 4;
+    const bool has_tail = (side & 3) != 0;
+    // table builders: thread t owns the window position e = t % NXP and the columns t / NXP, + ngrp, ...; its
+    // centre byte does not depend on the window row
+    constexpr int NGRP = (A3P * 64) / NXP;
+    const int te = (int)threadIdx.x % NXP, tg = (int)threadIdx.x / NXP;
+    int tx = xbase + te;
+    tx = tx < 0 ? 0 : (tx > Wp - side ? Wp - side : tx);   // positions no hypothesis uses: any in-image value
+    const unsigned tcb = Bimg[(size_t)wins * Wp + tx + wins];
+
+    for (int r = 0; r < side; r++) {
+        __syncthreads();                                   // previous row's table is no longer read (and s_color is in)
+        // T[c][e] = color[|B[r][x + c] - B[wins][x + wins]|] for the window position x = xbase + e
+        if (tg < NGRP) {
+            const uint8_t *brow = Bimg + (size_t)r * Wp + tx;
+            for (int c = tg; c < side; c += NGRP)
+                s_T[c * NXP + te] = s_color[__builtin_amdgcn_sad_u16((unsigned)brow[c], tcb, 0u)];
+        }
+        __syncthreads();
+        auto taps4 = [&](const unsigned (&word)[K], int c0, int keep_from) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int c = c0 + cc;
+                // wave-uniform operands through the scalar cache
+                double w = wrow[r * side + c];
+                const unsigned pa = arow[(size_t)r * Wp + c];
+                if (c < keep_from) w = 0.0;                // tail dword: columns already counted get weight 0
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const unsigned pb = (word[k] >> (8 * cc)) & 0xffu;
+                    const double c1 = tk[k][(size_t)c * NXP];
+                    unsigned e = __builtin_amdgcn_sad_u16(pa, pb, 0u);
+                    e = e > (unsigned)T ? (unsigned)T : e;
+                    const double m2 = w * c1;
+                    sw[k] = __builtin_fma(w, c1, sw[k]);
+                    sv[k] = __builtin_fma(m2, (double)e, sv[k]);
+                }
+            }
+        };
+        const uint8_t *brow = Bimg + (size_t)r * Wp;       // uniform row base + per-lane 32-bit position
+        for (int g = 0; g < nfull; g++) {
+            unsigned word[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], brow + 4 * g + xo[k], 4);
+            taps4(word, 4 * g, 0);
+        }
+        if (has_tail) {
+            unsigned word[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], brow + ctail + xo[k], 4);
+            taps4(word, ctail, 4 * nfull);
+        }
+    }
+    if (!live) return;
+    float cv[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) cv[k] = (float)(sv[k] / sw[k]);
+    // WinTakeAll: first strict minimum (:193-208); dmax < 0: see k_asw
+    float lm = INFINITY; int ld = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int d = lane + 64 * k;
+        if (d < D && lm > cv[k]) { lm = cv[k]; ld = d; }
+    }
+    const float m = wave_min_f32(lm);
+    int cand = (lm == m) ? ld : 0x7fffffff;
+    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+    const size_t p = (size_t)io * W + jo;
+    if (lane == 0) disp[p] = (dmax < 0) ? 0.0f : (float)cand;
+    if (cost_out) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int d = lane + 64 * k;
+            if (d < D) cost_out[p * D + d] = (dmax < 0) ? NAN : cv[k];
+        }
+    }
+}
+
 }  // namespace
+
+static int g_asw_impl = 3;                               // 3: k_asw_anchor + k_asw3 (default); 1: k_asw (first formulation)
+SMT_API int smt_asw_set_impl(int impl)
+{
+    if (impl != 1 && impl != 3) return SMT_ERR_ARG;
+    g_asw_impl = impl;
+    return SMT_OK;
+}
 
 SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winsize, int view,
                     int32_t *disp, void *stream)
@@ -356,9 +528,51 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         return SMT_ERR_ARG;
     const int wins = winSize + 1, side = 2 * wins + 1;
     if (side > 64) return SMT_ERR_ARG;                   // one window row per wave pass
-    const size_t shm = (size_t)(256 * 32 + side * side) * 8;
     const int N = H * W;
     const int v = view == SMT_VIEW_LEFT ? 0 : 1;
+    if (g_asw_impl == 3 && side >= 5) {
+        const int K = (D + 63) / 64, NXP = A3P + 64 * K;
+        const size_t shm3 = ((size_t)side * NXP + 256) * 8;
+        const size_t nt = (size_t)N * side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
+        hipStream_t st = smt_stream(stream);
+        double *w0 = nullptr;
+        unsigned *a32 = nullptr;
+        {
+            // keep the stream-ordered pool's memory between calls (the default releases it at every sync)
+            static bool pool_set = false;
+            if (!pool_set) {
+                int dev = 0; hipMemPool_t pool = nullptr;
+                unsigned long long keep = ~0ull;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                pool_set = true;
+            }
+        }
+        if (shm3 <= 160 * 1024 && hipMallocAsync((void **)&w0, nt * 8, st) == hipSuccess) {
+            if (hipMallocAsync((void **)&a32, na * 4, st) != hipSuccess) { (void)hipFreeAsync(w0, st); return SMT_ERR_ALLOC; }
+            const uint8_t *Ap = v == 0 ? Lp : Rp;
+            hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32);
+            const dim3 grid((W + A3P - 1) / A3P, H);
+#define SMT_ASW3(KK)                                                                                         \
+    do {                                                                                                     \
+        SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
+        hipLaunchKernelGGL(k_asw3<KK>, grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+    } while (0)
+            switch (K) {
+            case 1: SMT_ASW3(1); break;
+            case 2: SMT_ASW3(2); break;
+            case 3: SMT_ASW3(3); break;
+            default: SMT_ASW3(4); break;
+            }
+#undef SMT_ASW3
+            (void)hipFreeAsync(w0, st);
+            (void)hipFreeAsync(a32, st);
+            SMT_LAUNCH_CHECK();
+            return SMT_OK;
+        }
+        // table does not fit (LDS or device memory): the first formulation below
+    }
+    const size_t shm = (size_t)(256 * 32 + side * side) * 8;
 #define SMT_ASW(KK)                                                                                          \
     do {                                                                                                     \
         SMT_HIP(hipFuncSetAttribute((const void *)k_asw<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
