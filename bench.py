@@ -340,6 +340,9 @@ def main():
         roof["placement"] = {"candidate_pairs_tried": tries, "kept_pair_store_only_ms": round(place_ms, 4),
                              "note": "smt_adcensus_create keeps the fastest of up to 6 allocations of the two volumes "
                                      "(HBM write rate depends on the physical pages, DESIGN.md section 5)"}
+        plain, nt_ms, plain_ms = adc.store_mode()
+        roof["store_mode"] = {"chosen": "plain" if plain else "streaming (nt)", "calibration_nt_ms": round(nt_ms, 4),
+                              "calibration_plain_ms": round(plain_ms, 4)}
         roof["smi_before"] = smi_before
         roof["smi_after"] = smi_snapshot()
         out = {

@@ -125,6 +125,11 @@ int smt_adcensus_destroy(smt_adcensus *h);
  * environment disables the search.  tries = candidate pairs allocated, store_only_ms = the kept pair's
  * store-only time (0 when there was no search).  Either pointer may be NULL. */
 int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_only_ms);
+/* Which stores the both-views cost kernel uses on this handle: smt_adcensus_create times the kernel a few
+ * launches with streaming (non-temporal) and with ordinary stores and keeps ordinary ones only when they win by
+ * more than 2 % (a device property like the placement; SMT_STORE_MODE=nt|plain in the environment fixes it).
+ * plain = 1 / 0, nt_ms / plain_ms = the calibration times (0 when there was none).  Any pointer may be NULL. */
+int smt_adcensus_store_mode(smt_adcensus *h, int *plain, float *nt_ms, float *plain_ms);
 int smt_adcensus_set_stream(smt_adcensus *h, void *stream);
 
 /* ComputeADcensus (AD-Census.h:271-294) for SMT_VIEW_LEFT, ComputeADcensusRight

@@ -156,6 +156,12 @@ class AD_Census:
         check(lib().smt_adcensus_placement(self._h, C.byref(n), C.byref(ms)), "smt_adcensus_placement")
         return n.value, ms.value
 
+    def store_mode(self):
+        """(plain stores chosen?, calibration ms with streaming stores, with plain stores)."""
+        pl, a, b = C.c_int(), C.c_float(), C.c_float()
+        check(lib().smt_adcensus_store_mode(self._h, C.byref(pl), C.byref(a), C.byref(b)), "smt_adcensus_store_mode")
+        return bool(pl.value), a.value, b.value
+
     def diag(self, reps=20):
         """smt_adcensus_diag: (in-kernel shader clock in MHz, stamped cost-kernel ms, store-only ms)."""
         self._bind_stream()

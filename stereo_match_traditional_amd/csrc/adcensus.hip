@@ -349,20 +349,22 @@ constexpr int FPW = FTJ / 4;      // consecutive pixels per wave
 // larger than L2 + Infinity Cache, so they should not displace the tables the next workgroups read.
 // With the XCD-contiguous chunk order this is worth 5-6 % of the kernel (A/B); with chunks in
 // dispatch order it cost 4 %.
-template <int C>
+template <int C, bool NTS = true>
 __device__ __forceinline__ void st_stream(float *p, const float (&v)[C])
 {
     typedef float f2v __attribute__((ext_vector_type(2)));
     typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));   // rows of 192 floats: 12-byte lane stride
     typedef float f4v __attribute__((ext_vector_type(4)));
-    if (C == 1) __builtin_nontemporal_store(v[0], p);
-    else if (C == 2) { f2v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0]; __builtin_nontemporal_store(x, reinterpret_cast<f2v *>(p)); }
-    else if (C == 3) {
+    if (C == 1) { if (NTS) __builtin_nontemporal_store(v[0], p); else *p = v[0]; }
+    else if (C == 2) {
+        f2v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0];
+        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f2v *>(p)); else *reinterpret_cast<f2v *>(p) = x;
+    } else if (C == 3) {
         f3v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0]; x.z = v[C > 2 ? 2 : 0];
-        __builtin_nontemporal_store(x, reinterpret_cast<f3v *>(p));
+        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f3v *>(p)); else *reinterpret_cast<f3v *>(p) = x;
     } else {
         f4v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0]; x.z = v[C > 2 ? 2 : 0]; x.w = v[C > 3 ? 3 : 0];
-        __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p));
+        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p)); else *reinterpret_cast<f4v *>(p) = x;
     }
 }
 
@@ -372,7 +374,7 @@ struct __attribute__((aligned(16))) Anchor { uint64_t cen, mask; };
 // first hypothesis is >= D compute a harmless duplicate of lane 0, elements past D are neither
 // stored nor allowed to win the WTA, and the staged arrays carry XPAD spare entries on both sides for
 // the window slots those elements would touch.
-template <int C, int VIEW, bool FULL>
+template <int C, int VIEW, bool FULL, bool NTS = true>
 __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tables &T, float *__restrict__ vol,
                                                float *__restrict__ disp, int i, int bx)
 {
@@ -489,11 +491,11 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
                         vecf<C> pk;
 #pragma unroll
                         for (int k = 0; k < C; k++) pk.v[k] = c[k];
-                        st_stream<C>(out, pk.v);
+                        st_stream<C, NTS>(out, pk.v);
                     } else {
 #pragma unroll
                         for (int k = 0; k < C; k++)
-                            if (ok[k]) __builtin_nontemporal_store(c[k], out + k);
+                            if (ok[k]) { if (NTS) __builtin_nontemporal_store(c[k], out + k); else out[k] = c[k]; }
                     }
                     out += D;
                     if (disp) {
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(NT) k_cost_fast(int H, int W, int D, Tables T,
 }
 
 // both views in one launch (no gap / tail between two launches)
-template <int C, bool FULL>
+template <int C, bool FULL, bool NTS = true>
 __global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T, float *__restrict__ vol0,
                                                    float *__restrict__ vol1, float *__restrict__ disp0,
                                                    float *__restrict__ disp1, int nbx)
@@ -564,8 +566,8 @@ __global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T
     // (MI355X_MICROARCH.md, DVFS item 6).  Ordinary launches take the null branch and execute no stamp.
     unsigned long long t0 = 0, r0 = 0;
     if (T.stamp) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    if (view == 0) cost_fast_body<C, 0, FULL>(H, W, D, T, vol0, disp0, i, bx);
-    else cost_fast_body<C, 1, FULL>(H, W, D, T, vol1, disp1, i, bx);
+    if (view == 0) cost_fast_body<C, 0, FULL, NTS>(H, W, D, T, vol0, disp0, i, bx);
+    else cost_fast_body<C, 1, FULL, NTS>(H, W, D, T, vol1, disp1, i, bx);
     if (T.stamp && threadIdx.x == 0) {
         unsigned long long *s = T.stamp + 4 * (size_t)blockIdx.x;
         s[0] = t0; s[1] = r0; s[2] = __builtin_amdgcn_s_memtime(); s[3] = __builtin_amdgcn_s_memrealtime();
@@ -644,6 +646,8 @@ struct smt_adcensus {
     long n_seen;         // pairs processed since timing was (re-)enabled
     int timing_stride;   // every timing_stride-th pair is recorded
     bool *ev_merged;     // slot recorded 3 events (tables end == cost start, one stream)
+    bool plain_stores;   // both-views cost kernel with ordinary instead of streaming stores (chosen at create)
+    float store_mode_ms[2];   // calibration: kernel ms with streaming / plain stores (0: not calibrated)
     int place_tries;     // candidate volume pairs tried by place_volumes
     float place_ms;      // store-only time of the pair that was kept (0: no search)
 };
@@ -770,6 +774,74 @@ static int place_volumes(smt_adcensus *h)
     return SMT_OK;
 }
 
+template <int C, bool FULL>
+static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR);
+
+// Streaming (non-temporal) or ordinary stores for the volumes?  Streaming stores were worth 8-19 % on the
+// devices of round 1; on another device the store-only twin is 5 % FASTER with ordinary stores (DESIGN.md
+// section 4).  Like the placement this is a property of the device, so Initialize times the real both-views
+// kernel a few launches each way on the handle's own (zeroed) tables and volumes and keeps ordinary stores
+// only when they win by more than 2 %.  SMT_STORE_MODE=nt / plain in the environment fixes the choice.
+static void calibrate_store_mode(smt_adcensus *h)
+{
+    h->plain_stores = false; h->store_mode_ms[0] = h->store_mode_ms[1] = 0.0f;
+    const char *env = getenv("SMT_STORE_MODE");
+    if (env && env[0] == 'p') { h->plain_stores = true; return; }
+    if (env && env[0] == 'n') return;
+    const size_t V = (size_t)h->H * h->W * h->D;
+    if (h->D % 64 != 0 || V < ((size_t)1 << 22)) return;
+    const size_t N = (size_t)h->H * h->W;
+    // zeroed tables are valid inputs (census 0, bytes 0); the speed of a store-bound kernel does not depend on them
+    for (int t = 0; t < 2; t++) {
+        for (int v = 0; v < 2; v++) {
+            if (hipMemset(h->TS[t].cenA[v], 0, N * 8) != hipSuccess || hipMemset(h->TS[t].u8[v], 0, N) != hipSuccess ||
+                hipMemset(h->TS[t].cenX[v], 0, (size_t)h->H * h->TS[t].WX * 8) != hipSuccess) return;
+        }
+        if (hipMemset(h->TS[t].mask, 0, N * 8) != hipSuccess) return;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    const hipStream_t keep = h->stream;
+    h->stream = nullptr;
+    float best[2] = {1e30f, 1e30f};
+    for (int round = 0; round < 2; round++)                    // interleaved: nt, plain, nt, plain
+        for (int mode = 0; mode < 2; mode++) {
+            h->plain_stores = mode == 1;
+            const int reps = 4;
+            auto launch = [&]() {
+                switch (h->D / 64) {
+                case 1: launch_fast<1, true>(h, SMT_VIEW_BOTH, nullptr, nullptr); break;
+                case 2: launch_fast<2, true>(h, SMT_VIEW_BOTH, nullptr, nullptr); break;
+                case 3: launch_fast<3, true>(h, SMT_VIEW_BOTH, nullptr, nullptr); break;
+                default: launch_fast<4, true>(h, SMT_VIEW_BOTH, nullptr, nullptr); break;
+                }
+            };
+            launch();
+            (void)hipEventRecord(e0, nullptr);
+            for (int k = 0; k < reps; k++) launch();
+            (void)hipEventRecord(e1, nullptr);
+            float t = 1e30f;
+            if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess) t /= reps;
+            if (t < best[mode]) best[mode] = t;
+        }
+    h->stream = keep;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    h->store_mode_ms[0] = best[0]; h->store_mode_ms[1] = best[1];
+    h->plain_stores = best[1] < 0.98f * best[0];
+    // Initialize's contract: the volumes read as zeros until the first Compute* (AD-Census.h:341-342)
+    (void)hipMemset(h->vol[0], 0, V * 4); (void)hipMemset(h->vol[1], 0, V * 4);
+    (void)hipMemset(h->TS[0].flag, 0, 4);
+}
+
+SMT_API int smt_adcensus_store_mode(smt_adcensus *h, int *plain, float *nt_ms, float *plain_ms)
+{
+    if (!h) return SMT_ERR_ARG;
+    if (plain) *plain = h->plain_stores ? 1 : 0;
+    if (nt_ms) *nt_ms = h->store_mode_ms[0];
+    if (plain_ms) *plain_ms = h->store_mode_ms[1];
+    return SMT_OK;
+}
+
 SMT_API int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_only_ms)
 {
     if (!h) return SMT_ERR_ARG;
@@ -832,6 +904,7 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
         smt_adcensus_destroy(h);
         return SMT_ERR_HIP;
     }
+    calibrate_store_mode(h);
     *out = h;
     return SMT_OK;
 }
@@ -897,8 +970,12 @@ static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
     const int nbx = (h->W + FTJ - 1) / FTJ;
     auto blocks = [&](int nviews) { return dim3((unsigned)(((long)nbx * h->H * nviews + 7) / 8 * 8)); };
     if (views == SMT_VIEW_BOTH) {
-        hipLaunchKernelGGL((k_cost_fast2<C, FULL>), blocks(2), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
-                           h->vol[1], dL, dR, nbx);
+        if (h->plain_stores)
+            hipLaunchKernelGGL((k_cost_fast2<C, FULL, false>), blocks(2), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
+                               h->vol[1], dL, dR, nbx);
+        else
+            hipLaunchKernelGGL((k_cost_fast2<C, FULL, true>), blocks(2), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
+                               h->vol[1], dL, dR, nbx);
         return;
     }
     if (views & SMT_VIEW_LEFT)
@@ -1103,10 +1180,18 @@ SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float 
     // the real kernel with stamps, last, so that the volumes hold the pair's costs again afterwards
     for (int r = 0; r < reps; r++) {
         switch (C) {
-        case 1: hipLaunchKernelGGL((k_cost_fast2<1, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
-        case 2: hipLaunchKernelGGL((k_cost_fast2<2, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
-        case 3: hipLaunchKernelGGL((k_cost_fast2<3, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
-        default: hipLaunchKernelGGL((k_cost_fast2<4, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx); break;
+        case 1: if (h->plain_stores) hipLaunchKernelGGL((k_cost_fast2<1, true, false>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            else hipLaunchKernelGGL((k_cost_fast2<1, true, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            break;
+        case 2: if (h->plain_stores) hipLaunchKernelGGL((k_cost_fast2<2, true, false>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            else hipLaunchKernelGGL((k_cost_fast2<2, true, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            break;
+        case 3: if (h->plain_stores) hipLaunchKernelGGL((k_cost_fast2<3, true, false>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            else hipLaunchKernelGGL((k_cost_fast2<3, true, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            break;
+        default: if (h->plain_stores) hipLaunchKernelGGL((k_cost_fast2<4, true, false>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            else hipLaunchKernelGGL((k_cost_fast2<4, true, true>), dim3(nblk), dim3(NT), 0, h->stream, h->H, h->W, D, T, h->vol[0], h->vol[1], (float *)nullptr, (float *)nullptr, nbx);
+            break;
         }
     }
     SMT_HIP(hipEventRecord(e[2], h->stream));

@@ -268,3 +268,39 @@ def test_kernel_timing_ring(smt):
     prep, cost = adc.kernel_times()
     assert len(cost) == 3 and all(0 < t < 50 for t in prep + cost)
     adc.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "nt"])
+def test_store_mode_does_not_change_results(smt, O, mode, monkeypatch):
+    """The both-views kernel with ordinary and with streaming stores (a per-device choice made at Initialize,
+    forced here through SMT_STORE_MODE) writes the same volumes and maps; placement search on."""
+    monkeypatch.setenv("SMT_STORE_MODE", mode)
+    H, W, D = 40, 200, 192
+    L, R = O.synth_pair(H, W, D, 12)
+    Lf = torch.from_numpy(L.astype(np.float32)).to(dev())
+    Rf = torch.from_numpy(R.astype(np.float32)).to(dev())
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+    assert adc.store_mode()[0] == (mode == "plain")
+    dl = torch.empty((H, W), device=dev())
+    dr = torch.empty((H, W), device=dev())
+    adc.ComputeBoth(dl, dr)
+    adc.status()
+    ol = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
+    orr = O.adcensus_view(L, R, D, 10.0, 30.0, 1)
+    assert np.array_equal(adc.GetPtrLeft().cpu().numpy().view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(adc.GetPtrRight().cpu().numpy().view(np.uint32), orr.view(np.uint32))
+    assert np.array_equal(dl.cpu().numpy(), O.wta(ol)) and np.array_equal(dr.cpu().numpy(), O.wta(orr))
+    adc.close()
+
+
+def test_calibrated_handle_still_starts_zeroed(smt):
+    """Placement search and store-mode calibration write to the volumes during Initialize; they must read as
+    zeros afterwards like the reference's value-initialised `new float[]()` (AD-Census.h:341-342)."""
+    H, W, D = 270, 480, 64                       # big enough for both searches to run
+    z = torch.zeros((H, W), device=dev())
+    adc = smt.AD_Census().Initialize(z, z, D, H, W, 10.0, 30.0)
+    assert adc.placement()[0] >= 1
+    assert int(adc.GetPtrLeft().view(torch.int32).abs().max()) == 0
+    assert int(adc.GetPtrRight().view(torch.int32).abs().max()) == 0
+    adc.status()
+    adc.close()
