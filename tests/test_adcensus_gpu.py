@@ -277,12 +277,12 @@ def test_store_mode_does_not_change_results(smt, O, mode, monkeypatch):
     monkeypatch.setenv("SMT_STORE_MODE", mode)
     H, W, D = 40, 200, 192
     L, R = O.synth_pair(H, W, D, 12)
-    Lf = torch.from_numpy(L.astype(np.float32)).to(dev())
-    Rf = torch.from_numpy(R.astype(np.float32)).to(dev())
+    Lf = torch.from_numpy(L.astype(np.float32)).to(torch.device("cuda:0"))
+    Rf = torch.from_numpy(R.astype(np.float32)).to(torch.device("cuda:0"))
     adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
     assert adc.store_mode()[0] == (mode == "plain")
-    dl = torch.empty((H, W), device=dev())
-    dr = torch.empty((H, W), device=dev())
+    dl = torch.empty((H, W), device=torch.device("cuda:0"))
+    dr = torch.empty((H, W), device=torch.device("cuda:0"))
     adc.ComputeBoth(dl, dr)
     adc.status()
     ol = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
@@ -297,7 +297,7 @@ def test_calibrated_handle_still_starts_zeroed(smt):
     """Placement search and store-mode calibration write to the volumes during Initialize; they must read as
     zeros afterwards like the reference's value-initialised `new float[]()` (AD-Census.h:341-342)."""
     H, W, D = 270, 480, 64                       # big enough for both searches to run
-    z = torch.zeros((H, W), device=dev())
+    z = torch.zeros((H, W), device=torch.device("cuda:0"))
     adc = smt.AD_Census().Initialize(z, z, D, H, W, 10.0, 30.0)
     assert adc.placement()[0] >= 1
     assert int(adc.GetPtrLeft().view(torch.int32).abs().max()) == 0
