@@ -213,6 +213,16 @@ def extra_configs(dev, reps=5):
     for o in (adc, caL, caR, so):
         o.close()
     del aggL, aggR, sout
+    # the same pipeline through the one batched C-ABI entry (smt_pipeline_run_batch, 3 pairs per call):
+    # launch gaps, staging and the device-side counts included, no host read-back
+    pipe = smt.Pipeline(H, W, D, dev)
+    Lb3, Rb3 = torch.stack([Lu] * 3), torch.stack([Ru] * 3)
+    call_ms = ev_timed(lambda: pipe.run(Lb3, Rb3), 2) / 3
+    pipe.status()
+    pipe.close()
+    out["cfg3_pipeline_1080p_d192"]["batched_entry_ms_per_pair"] = round(call_ms, 4)
+    out["cfg3_pipeline_1080p_d192"]["batched_entry_frac_hbm_peak"] = round(68 * V / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    del Lb3, Rb3
 
     # ---- config 4: ASW 35x35 (winSize 16), 960x540, D=128, left view ------------------------------
     H, W, D, ws = 540, 960, 128, 16

@@ -211,7 +211,7 @@ int smt_crossarm_arms(smt_crossarm *h, const uint8_t *img, int channels);
  * another order -- which changes the sticky-threshold chain (`_tao` is lowered at CrossArm.cpp:223-225 by
  * whichever call first walks past sec_length and stays lowered for every later pixel and call):
  *   smt_crossarm_reset    = the state part of Initialize (CrossArm.cpp:13-17): threshold back to tau, the
- *                           four maps zeroed (also clears the UB flag);
+ *                           four maps zeroed;
  *   smt_crossarm_arm_dir  = ComputeLeftArmLength (dir 0, :147-260), ComputeRightArmLength (1, :262-373),
  *                           ComputeTopArmLength (2, :375-486), ComputeButtonArmLength (3, :488-598) with
  *                           the threshold as the previous call left it;
@@ -243,7 +243,7 @@ int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, i
 int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out, int order,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
-                                             plane since the previous status call / reset / arms */
+                                             plane (or, order 2, were empty) since the previous status call */
 /* Test / tuning hook: which aggregation kernel runs.  7 = 2x8 pixels per wave, every tap of the
  * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
  * a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
@@ -312,6 +312,35 @@ int smt_scanline_run(smt_scanline *h, const float *vol_in, const float *gray, fl
  * pass: 0 left->right (isLeft=true), 1 right->left, 2 top->bottom (isUp=true), 3 bottom->top. */
 int smt_scanline_pass(smt_scanline *h, const float *vol_in, const float *gray, int pass,
                       float *vol_out);
+
+/* =====================================================================================
+ * The whole AD-CensusV1/main.cpp pipeline, batched      (SURVEY 8b "batch variants"; BASELINE configs[2])
+ * ===================================================================================== */
+typedef struct smt_pipeline smt_pipeline;
+typedef struct smt_pipeline_params {
+    float sigmaC, sigmaS;   /* 10, 30   main.cpp:25-26 */
+    int tao, p1, p2, gate;  /* 30, 10, 150, 2   main.cpp:27-30 */
+} smt_pipeline_params;
+void smt_pipeline_default_params(smt_pipeline_params *p);
+/* Owns one AD_Census, one CrossArmAggregation, one ScanlineOptimizer and the three volumes between them. */
+int smt_pipeline_create(int H, int W, int D, const smt_pipeline_params *p, smt_pipeline **out);
+int smt_pipeline_create_on(int device, int H, int W, int D, const smt_pipeline_params *p, smt_pipeline **out);
+int smt_pipeline_destroy(smt_pipeline *h);
+int smt_pipeline_set_stream(smt_pipeline *h, void *stream);
+/* main.cpp:46-92 for `pairs` pairs of uint8 gray images [pairs][H][W] (the images after cvtColor, :19-20), in
+ * main.cpp's order with lines 86-89 and 92 enabled: float copies, ComputeADcensus(+Right), CrossArm
+ * Initialize + four arm passes + AggregationVertical + WTA on the left and on the right image,
+ * ScanlineOptimizer on the LEFT aggregated volume + WTA, LeftRightConsistency(gate).
+ *   dispL   float32 [pairs][H][W]: the scanline WTA map after the LR check (+inf = rejected)
+ *   dispR   float32 [pairs][H][W]: WTA of the aggregated right volume (main.cpp:84)
+ *   cls     uint8   [pairs][H][W] as smt_lrcheck;  counts int32 [pairs][2] (may be NULL)
+ * Asynchronous on the handle's stream.  The volumes are reused per pair (smt_pipeline_volumes: the last
+ * pair's, borrowed).  This is the sharding unit for the pair axis of config 3. */
+int smt_pipeline_run_batch(smt_pipeline *h, const uint8_t *grayL, const uint8_t *grayR, int pairs,
+                           float *dispL, float *dispR, uint8_t *cls, int *counts);
+int smt_pipeline_volumes(smt_pipeline *h, float **cost_left, float **cost_right, float **agg_left,
+                         float **agg_right, float **scanline_sum);
+int smt_pipeline_status(smt_pipeline *h); /* synchronising: SMT_ERR_DOMAIN / SMT_ERR_REF_UB seen since the last call */
 
 /* =====================================================================================
  * Left-right consistency              replaces LeftRightConsistency

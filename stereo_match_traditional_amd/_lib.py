@@ -27,6 +27,11 @@ class CrossArmParams(C.Structure):
                 ("max_length", C.c_int), ("chain_tau", C.c_int), ("quirks", C.c_uint)]
 
 
+class PipelineParams(C.Structure):
+    _fields_ = [("sigmaC", C.c_float), ("sigmaS", C.c_float), ("tao", C.c_int), ("p1", C.c_int), ("p2", C.c_int),
+                ("gate", C.c_int)]
+
+
 class ADCensusOption(C.Structure):
     """struct ADCensusOption (CBLSM/adcensus_types.h:45-75)."""
     _fields_ = [("min_disparity", C.c_int32), ("max_disparity", C.c_int32), ("lambda_ad", C.c_int32),

@@ -15,7 +15,7 @@ __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "choose
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
            "AdaptiveSupportWeight", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
-           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate"]
+           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline"]
 
 
 def current_stream_ptr():
@@ -763,3 +763,59 @@ def adcensus_option_aggregate(option, bytes_left, dispVolum, num_iters=4, want_d
     check(lib().smt_adcensus_option_aggregate(C.byref(option), _ptr(bytes_left), _ptr(dispVolum), W, H, int(num_iters),
                                               _ptr(cost), _ptr(disp), current_stream_ptr()), "smt_adcensus_option_aggregate")
     return cost, disp
+
+
+# ======================================================================================
+# The whole AD-CensusV1/main.cpp pipeline, batched (smt_pipeline_*)
+# ======================================================================================
+class Pipeline:
+    """main.cpp:46-92 (scanline and LR check enabled) for batches of gray pairs; the sharding unit of config 3."""
+
+    def __init__(self, row, col, dispRange, device=None, **params):
+        self.row, self.col, self.dispRange = int(row), int(col), int(dispRange)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        p = _lib.PipelineParams()
+        lib().smt_pipeline_default_params(C.byref(p))
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        h = C.c_void_p()
+        check(lib().smt_pipeline_create(self.row, self.col, self.dispRange, C.byref(p), C.byref(h)), "smt_pipeline_create")
+        self._h = h
+
+    def run(self, grayL, grayR):
+        """uint8 [pairs][row][col] (or [row][col]) -> (dispL after LR check, dispR, cls, counts[pairs][2])."""
+        if grayL.dim() == 2:
+            grayL, grayR = grayL[None], grayR[None]
+        P = grayL.shape[0]
+        _dev(grayL, torch.uint8, (P, self.row, self.col), "grayL")
+        _dev(grayR, torch.uint8, (P, self.row, self.col), "grayR")
+        dl = torch.empty((P, self.row, self.col), dtype=torch.float32, device=grayL.device)
+        dr = torch.empty_like(dl)
+        cls = torch.empty((P, self.row, self.col), dtype=torch.uint8, device=grayL.device)
+        counts = torch.zeros((P, 2), dtype=torch.int32, device=grayL.device)
+        check(lib().smt_pipeline_set_stream(self._h, current_stream_ptr()), "smt_pipeline_set_stream")
+        check(lib().smt_pipeline_run_batch(self._h, _ptr(grayL), _ptr(grayR), P, _ptr(dl), _ptr(dr), _ptr(cls), _ptr(counts)),
+              "smt_pipeline_run_batch")
+        return dl, dr, cls, counts
+
+    def volumes(self):
+        ps = [C.c_void_p() for _ in range(5)]
+        check(lib().smt_pipeline_volumes(self._h, *[C.byref(p) for p in ps]), "smt_pipeline_volumes")
+        shp = (self.row, self.col, self.dispRange)
+        return [_view_of(p.value, shp, torch.float32, self.device) for p in ps]
+
+    def status(self):
+        check(lib().smt_pipeline_status(self._h), "smt_pipeline_status")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            lib().smt_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

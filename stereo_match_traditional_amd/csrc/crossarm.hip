@@ -1222,7 +1222,6 @@ SMT_API int smt_crossarm_reset(smt_crossarm *h)
     // with the stride bug most of rightLength stays 0.
     for (int k = 0; k < 4; k++) SMT_HIP(hipMemsetAsync(h->arm[k], 0, N * 4, h->stream));
     SMT_HIP(hipMemcpyAsync(h->flip + 5, &h->P.tau, 4, hipMemcpyHostToDevice, h->stream));   // `_tao = tao` (:13)
-    SMT_HIP(hipMemsetAsync(h->flip + 4, 0, 4, h->stream));                                   // UB flag of the last cycle
     h->have_arms = true;
     return SMT_OK;
 }

@@ -71,3 +71,18 @@ def adcensus_batch(L, R, D, sigmaC=10.0, sigmaS=30.0):
     adc.status()
     adc.close()
     return dl, dr
+
+
+def pipeline_batch(L8, R8, D, **params):
+    """`compute` for run_sharded on configs[2]: the whole main.cpp pipeline (smt_pipeline_run_batch) for a
+    [count, H, W] uint8 shard on this rank's GPU -> (LR-checked left maps, right maps)."""
+    from .api import Pipeline
+    c, H, W = L8.shape
+    if c == 0:
+        z = torch.empty((0, H, W), dtype=torch.float32, device=L8.device)
+        return z, z.clone()
+    pipe = Pipeline(H, W, D, L8.device, **params)
+    dl, dr, _, _ = pipe.run(L8.contiguous(), R8.contiguous())
+    pipe.status()
+    pipe.close()
+    return dl, dr
