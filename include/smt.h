@@ -402,6 +402,9 @@ int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int t2);
  * cost_init: float32 [H][W][D].  The result stays in the handle (get_cost_ptr). */
 int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img_left, const float *cost_init,
                            int num_iters);
+/* Test hook: 2 = shared-tap passes (16 pixels per wave along the pass axis, default), 1 = one pixel per wave
+ * (first formulation).  Identical bits. */
+int smt_crossagg_set_impl(smt_crossagg *h, int impl);
 /* get_cost_ptr (:125-133) / get_arms_ptr (:120-123): borrowed. arms: uint8 [H][W][4] =
  * left,right,top,bottom (struct CrossArm, cross_aggregator.h:17-20). */
 int smt_crossagg_cost(smt_crossagg *h, float **cost);

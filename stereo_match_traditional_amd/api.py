@@ -550,6 +550,10 @@ class CrossAggregator:
         check(lib().smt_crossagg_aggregate(self._h, _ptr(self._img), _ptr(self._cost), int(num_iters)),
               "smt_crossagg_aggregate")
 
+    def set_impl(self, impl):
+        """2 = shared-tap passes (default), 1 = one pixel per wave (test hook)."""
+        check(lib().smt_crossagg_set_impl(self._h, int(impl)), "smt_crossagg_set_impl")
+
     def get_cost_ptr(self):
         p = C.c_void_p()
         check(lib().smt_crossagg_cost(self._h, C.byref(p)), "smt_crossagg_cost")

@@ -108,6 +108,143 @@ __global__ void __launch_bounds__(NT) k_ca_pass(const float *__restrict__ src, f
         if (dl + k < D) o[k] = FINAL ? acc[k] / n : acc[k];
 }
 
+// ---- shared-tap pass (default) --------------------------------------------------------------------------
+// k_ca_pass above loads every tap of every pixel (arm sum ~20 taps x 64*C*4 bytes through the L1 per pixel and
+// pass: 1.4-2.1 ms per pass at 1280x720x128).  The sums are one-dimensional, so the register-sharing scheme of
+// the rectangle aggregation (crossarm.hip, k_aggregate_multi) applies in its simplest form: one wave owns 16
+// consecutive pixels ALONG the pass axis, walks the union of their tap intervals [q - a_q, q + b_q] once in
+// increasing order -- the reference's order for every pixel (t = -arm .. +arm, cross_aggregator.cpp:342-392) --
+// and adds each tap to all 16 accumulators as fma(x, f, acc), f = 1.0f for the pixels whose interval holds it
+// and 0.0f for the others (fma(x, 1, acc) is the reference's acc + x, fma(x, 0, acc) is acc bit for bit for
+// finite x; a pixel whose result is NaN is recomputed by the plain walk, which is the reference's answer in every
+// case).  The membership of a tap is one ballot; its 16 flags are two rows of the 256 x 8 table; 4-pixel groups
+// without a member are skipped.  16 + a + b taps instead of 16 x (a + b + 1).
+constexpr int CAP = 16;
+typedef float caf2 __attribute__((ext_vector_type(2)));
+typedef int cai2 __attribute__((ext_vector_type(2)));
+typedef int cai3 __attribute__((ext_vector_type(3)));
+typedef int cai4 __attribute__((ext_vector_type(4)));
+
+template <int C, bool HORIZ, bool FINAL, bool FULL>
+__global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, float *__restrict__ dst, int W, int H,
+                                                 int D, const uint8_t *__restrict__ arms, const uint16_t *__restrict__ cnt,
+                                                 const float *__restrict__ member)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wid = (long)blockIdx.x * (NT / 64) + wv;
+    int x0, y0, npx;
+    if (HORIZ) {
+        const int nxb = (W + CAP - 1) / CAP;
+        y0 = (int)(wid / nxb); x0 = (int)(wid % nxb) * CAP;
+        if (y0 >= H) return;
+        npx = min(CAP, W - x0);
+    } else {
+        const int nyb = (H + CAP - 1) / CAP;               // consecutive waves = consecutive columns of one row band
+        const long yb = wid / W;
+        x0 = (int)(wid % W); y0 = (int)yb * CAP;
+        if (yb >= nyb) return;
+        npx = min(CAP, H - y0);
+    }
+    const long stride = HORIZ ? 1 : W;
+    const long p0 = (long)y0 * W + x0;
+    // lane q: tap interval of pixel q relative to the first pixel; empty past the tile
+    int lo = 1, hi = 0;
+    if (lane < npx) {
+        const uchar4 a = reinterpret_cast<const uchar4 *>(arms)[p0 + lane * stride];
+        lo = lane - (HORIZ ? (int)a.x : (int)a.z);
+        hi = lane + (HORIZ ? (int)a.y : (int)a.w);
+    }
+    int umin = 0, umax = npx - 1;                           // every pixel holds its own position
+#pragma unroll
+    for (int q = 0; q < CAP; q++) {
+        if (q < npx) {
+            umin = min(umin, __builtin_amdgcn_readlane(lo, q));
+            umax = max(umax, __builtin_amdgcn_readlane(hi, q));
+        }
+    }
+    const int dl = lane * C;
+    caf2 acc[CAP / 2][C];
+#pragma unroll
+    for (int j = 0; j < CAP / 2; j++)
+#pragma unroll
+        for (int k = 0; k < C; k++) acc[j][k] = caf2{0.0f, 0.0f};
+    auto ld = [&](long pix, float (&x)[C]) {
+        const float *sp = src + pix * D + dl;
+        if (FULL) {
+            if (C == 1) x[0] = sp[0];
+            else if (C == 2) { const cai2 v = *reinterpret_cast<const cai2 *>(sp); x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y); }
+            else if (C == 3) {
+                x[0] = sp[0]; x[C > 1 ? 1 : 0] = sp[C > 1 ? 1 : 0]; x[C > 2 ? 2 : 0] = sp[C > 2 ? 2 : 0];
+            } else {
+                const cai4 v = *reinterpret_cast<const cai4 *>(sp);
+                x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y);
+                x[C > 2 ? 2 : 0] = __int_as_float(v.z); x[C > 3 ? 3 : 0] = __int_as_float(v.w);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++) x[k] = (dl + k < D) ? sp[k] : 0.0f;
+        }
+    };
+    auto add_flagged = [&](unsigned m, const float (&x)[C]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned mb = (m >> (8 * h)) & 255u;
+            const float *f = member + mb * 8u;
+            auto pair = [&](int j) {
+                const caf2 fl = caf2{f[2 * j], f[2 * j + 1]};
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    acc[4 * h + j][c] = __builtin_elementwise_fma(caf2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+            };
+            if (mb & 0x0fu) { pair(0); pair(1); }
+            if (mb & 0xf0u) { pair(2); pair(3); }
+        }
+    };
+    constexpr int G = 4;                                    // taps loaded ahead of their adds
+    for (int u0 = umin; u0 <= umax; u0 += G) {
+        unsigned m[G];
+        float x[G][C];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const int u = min(u0 + k, umax);                // a short last group repeats its last tap with no member
+            m[k] = (u0 + k <= umax) ? (unsigned)__ballot(lo <= u && u <= hi) : 0u;
+            ld(p0 + u * stride, x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) add_flagged(m[k], x[k]);
+    }
+    // finish: plain walk for pixels whose sum is NaN (a non-finite tap times a zero flag, or a genuine NaN)
+#pragma unroll
+    for (int q = 0; q < CAP; q++) {
+        if (q >= npx) continue;
+        float a[C];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            a[k] = (q & 1) ? acc[q / 2][k].y : acc[q / 2][k].x;
+            bad = bad || (a[k] != a[k]);
+        }
+        const long p = p0 + q * stride;
+        if (__ballot(bad)) {
+            const int qlo = __builtin_amdgcn_readlane(lo, q), qhi = __builtin_amdgcn_readlane(hi, q);
+#pragma unroll
+            for (int k = 0; k < C; k++) a[k] = 0.0f;
+            for (int u = qlo; u <= qhi; u++) {
+                float x[C];
+                ld(p0 + u * stride, x);
+#pragma unroll
+                for (int k = 0; k < C; k++) a[k] = a[k] + x[k];
+            }
+        }
+        float *o = dst + p * D + dl;
+        const float n = FINAL ? (float)cnt[p] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < C; k++)
+            if (FULL || dl + k < D) o[k] = FINAL ? a[k] / n : a[k];
+    }
+}
+
 }  // namespace
 
 struct smt_crossagg {
@@ -118,6 +255,8 @@ struct smt_crossagg {
     float *cur, *tmp;
     uint8_t *arms;
     uint16_t *cnt[2];
+    float *member;       // 256 x 8 membership flags (row m: 1.0f where bit q of m is set)
+    int impl;            // 2: shared-tap passes (default), 1: one pixel per wave (first formulation)
 };
 
 SMT_API int smt_crossagg_create(int W, int H, int D, smt_crossagg **out)
@@ -135,7 +274,15 @@ SMT_API int smt_crossagg_create(int W, int H, int D, smt_crossagg **out)
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->arms, N * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->cnt[0], N * 2);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->cnt[1], N * 2);
+    if (rc == SMT_OK) rc = smt_malloc((void **)&h->member, 256 * 8 * 4);
     if (rc != SMT_OK) { smt_crossagg_destroy(h); return rc; }
+    {
+        float tab[256 * 8];
+        for (int m = 0; m < 256; m++)
+            for (int q = 0; q < 8; q++) tab[m * 8 + q] = ((m >> q) & 1) ? 1.0f : 0.0f;
+        if (hipMemcpy(h->member, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { smt_crossagg_destroy(h); return SMT_ERR_HIP; }
+    }
+    h->impl = 2;
     *out = h;
     return SMT_OK;
 }
@@ -154,6 +301,7 @@ SMT_API int smt_crossagg_destroy(smt_crossagg *h)
     smt_dev_guard dev_guard(h->device);
     (void)hipFree(h->cur); (void)hipFree(h->tmp); (void)hipFree(h->arms);
     (void)hipFree(h->cnt[0]); (void)hipFree(h->cnt[1]);
+    (void)hipFree(h->member);
     delete h;
     return SMT_OK;
 }
@@ -174,9 +322,28 @@ SMT_API int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int
     return SMT_OK;
 }
 
+template <int C, bool FULL>
+static void ca_iter2(smt_crossagg *h, bool hfirst)
+{
+    const long nh = (long)h->H * ((h->W + CAP - 1) / CAP), nv = (long)h->W * ((h->H + CAP - 1) / CAP);   // waves per pass
+    dim3 gh((unsigned)((nh + 3) / 4)), gv((unsigned)((nv + 3) / 4));
+    const uint16_t *cnt = h->cnt[hfirst ? 0 : 1];
+    if (hfirst) {
+        hipLaunchKernelGGL((k_ca_pass2<C, true, false, FULL>), gh, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
+        hipLaunchKernelGGL((k_ca_pass2<C, false, true, FULL>), gv, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H, h->D, h->arms, cnt, h->member);
+    } else {
+        hipLaunchKernelGGL((k_ca_pass2<C, false, false, FULL>), gv, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
+        hipLaunchKernelGGL((k_ca_pass2<C, true, true, FULL>), gh, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H, h->D, h->arms, cnt, h->member);
+    }
+}
+
 template <int C>
 static void ca_iter(smt_crossagg *h, bool hfirst)
 {
+    if (h->impl == 2) {
+        if (h->D == 64 * C) ca_iter2<C, true>(h, hfirst); else ca_iter2<C, false>(h, hfirst);
+        return;
+    }
     const int N = h->W * h->H;
     dim3 grid((N + 3) / 4);
     const uint16_t *cnt = h->cnt[hfirst ? 0 : 1];
@@ -214,6 +381,13 @@ SMT_API int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img, const fl
         hfirst = !hfirst;
     }
     SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
+SMT_API int smt_crossagg_set_impl(smt_crossagg *h, int impl)
+{
+    if (!h || (impl != 1 && impl != 2)) return SMT_ERR_ARG;
+    h->impl = impl;
     return SMT_OK;
 }
 
