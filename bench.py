@@ -224,6 +224,21 @@ def extra_configs(dev, reps=5):
     out["cfg3_pipeline_1080p_d192"]["batched_entry_frac_hbm_peak"] = round(68 * V / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del Lb3, Rb3
 
+    # ---- CrossAggregator (named in north_star): 4 iterations x 2 passes at 1280x720, D=128 ----
+    H, W, D = 720, 1280, 128
+    L, R = synth.synth_pair(H, W, D, 2)
+    bgr = T(np.repeat(L[..., None], 3, axis=2))
+    cost0 = torch.rand((H, W, D), device=dev)
+    ca = smt.CrossAggregator()
+    ca.Initialize(W, H, 0, D, dev)
+    ca.SetData(bgr, bgr, cost0)
+    ca.SetParams(34, 17, 20, 6)
+    ms = ev_timed(lambda: ca.Aggregate(4), 3)
+    ca.close()
+    out["a18_crossaggregator_720p_d128"] = {"ms_4_iterations": round(ms, 3), "alg_bytes_per_hyp": 64,
+                                            "frac_hbm_peak": round(64.0 * H * W * D / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del bgr, cost0
+
     # ---- config 4: ASW 35x35 (winSize 16), 960x540, D=128, left view ------------------------------
     H, W, D, ws = 540, 960, 128, 16
     L, R = synth.synth_pair(H, W, D, 4)
