@@ -639,7 +639,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
 template <int C, int ORDER, bool FULL, int QR, int SKIP>
-__global__ void __launch_bounds__(NT) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ void __launch_bounds__(NT, 6) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
@@ -1397,12 +1397,13 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     if (!h || !vin || !vout || vin == vout || order < 0 || order > 2) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 4 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership
-    // flags, groups of 4 pixels without a member skipped (default); 5 = the same without the skip;
-    // 3 = 1x8 pixels, no skip; 0 = 4 adjacent pixels per wave with a
-    // 16-way switch on the membership mask; 1 = plain one-pixel-per-wave walk (also the form used for
-    // volumes >= 4 GiB); 2 = pipelined one-pixel-per-wave walk.  All but 1 address taps with 32-bit
-    // byte offsets.
+    // variant: 7 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership flags,
+    // groups of 4 pixels without a member skipped, flag rows prefetched, per-axis membership tables, the
+    // four waves of a workgroup in lock-step (default); 6 = the same free-running; 4 = 6 with flags per live
+    // group and pixel-by-pixel classification; 5 = 4 without the skip; 3 = 1x8 pixels, no skip; 0 = 4
+    // adjacent pixels per wave with a 16-way switch on the membership mask; 1 = plain one-pixel-per-wave
+    // walk (also the form used for volumes >= 4 GiB and for order 2); 2 = pipelined one-pixel-per-wave
+    // walk.  All but 1 address taps with 32-bit byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
     if (order == 2) { launch_agg<2>(h, vin, vout, disp); SMT_LAUNCH_CHECK(); return SMT_OK; }   // inactive sibling: plain walk only
