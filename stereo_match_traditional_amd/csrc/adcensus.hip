@@ -1059,7 +1059,12 @@ SMT_API int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R
     return adcensus_pair(h, L, R, views, dispL, dispR, false);
 }
 
-static bool overlap_pays(const smt_adcensus *h) { return (size_t)h->H * h->W <= (size_t)1500000; }
+static bool overlap_pays(const smt_adcensus *h)
+{
+    const char *env = getenv("SMT_OVERLAP");             // tuning hook: 0 / 1 forces the choice
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    return (size_t)h->H * h->W <= (size_t)1500000;
+}
 
 SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
                                        int views, float *dispL, float *dispR)

@@ -539,13 +539,14 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         unsigned *a32 = nullptr;
         {
             // keep the stream-ordered pool's memory between calls (the default releases it at every sync)
-            static bool pool_set = false;
-            if (!pool_set) {
-                int dev = 0; hipMemPool_t pool = nullptr;
+            static bool pool_set[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !pool_set[dev]) {
+                hipMemPool_t pool = nullptr;
                 unsigned long long keep = ~0ull;
-                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+                if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
                     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                pool_set = true;
+                pool_set[dev] = true;
             }
         }
         if (shm3 <= 160 * 1024 && hipMallocAsync((void **)&w0, nt * 8, st) == hipSuccess) {
