@@ -82,6 +82,10 @@ int smt_stream_create(void **stream);
 int smt_stream_destroy(void *stream);
 int smt_stream_sync(void *stream); /* synchronising */
 
+/* float64 sum of a float32 device array into *out_dev (device double; zeroed on the stream first) -- the
+ * per-device term of the gather checksum of the batched multi-GPU configuration. */
+int smt_sum_f32(const float *x, size_t n, double *out_dev, void *stream);
+
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------
  * When enabled, every N-th pair processed on the handle records HIP events -- around the table
  * kernels on the handle's internal stream and around the cost kernel(s) on the caller's stream, i.e.

@@ -62,6 +62,11 @@ def build_host():
         exe = os.path.join(HERE, "lib", name)
         cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(HERE, "host", name + ".cpp"),
                "-o", exe, "-L" + os.path.join(HERE, "lib"), "-lsmt_hip", "-Wl,-rpath,$ORIGIN"]
+        if name == "adcensus_main":
+            # the batched configuration's exchange goes over RCCL (single process, one communicator per device)
+            rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+            cmd += ["-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"),
+                    "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-Wno-unused-result", "-Wno-deprecated-declarations"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("host build failed:\n" + r.stdout + r.stderr)

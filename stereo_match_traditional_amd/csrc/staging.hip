@@ -93,6 +93,30 @@ SMT_API int smt_u8_to_f32(const uint8_t *src, int H, int W, float *dst, void *st
     return SMT_OK;
 }
 
+// float64 sum of a float32 array (the checksum of the multi-GPU gather): per-wave DPP-free
+// shuffle reduction + one atomic per workgroup.  *out_dev is zeroed on the stream first.
+__global__ void __launch_bounds__(256) k_sum_f32(const float *__restrict__ x, size_t n, double *out)
+{
+    double acc = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) acc += (double)x[k];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+}
+
+SMT_API int smt_sum_f32(const float *x, size_t n, double *out_dev, void *stream)
+{
+    if (!x || !out_dev) return SMT_ERR_ARG;
+    SMT_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), smt_stream(stream)));
+    if (n == 0) return SMT_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_sum_f32, dim3(blocks), dim3(256), 0, smt_stream(stream), x, n, out_dev);
+    SMT_LAUNCH_CHECK();
+    return SMT_OK;
+}
+
 SMT_API int smt_median_filter(const float *in, float *out, int W, int H, int wnd_size, void *stream)
 {
     if (!in || !out || in == out || H <= 0 || W <= 0 || wnd_size < 1 || wnd_size > 7) return SMT_ERR_ARG;

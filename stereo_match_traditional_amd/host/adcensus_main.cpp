@@ -6,10 +6,13 @@
 //          adcensus_main --images left.png right.png D [disparity_out.png]     (imread -> cvtColor -> pipeline
 //                                                     -> imwrite, the file path of main.cpp:16-20, :115-117)
 //          adcensus_main --batch pairs H W D             (config 5 on every visible GPU, one handle per device)
+//          adcensus_main --batch-rccl pairs H W D        (the same with the maps exchanged by ncclAllGather and a
+//                                                         checksum ncclAllReduce over RCCL / xGMI)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#define SMT_HOST_WITH_RCCL
 #include "smt_host.hpp"
 
 static double g_hash_ms = 0;   // time spent hashing products, excluded from the pipeline figure
@@ -45,7 +48,7 @@ static void synth(int H, int W, int D, uint32_t seed, std::vector<unsigned char>
     }
 }
 
-static int batch_main(int pairs, int row, int col, int dispRange)
+static int batch_main(int pairs, int row, int col, int dispRange, bool rccl = false)
 {
     const size_t n = (size_t)row * col;
     std::vector<float> L((size_t)pairs * n), R((size_t)pairs * n), dl((size_t)pairs * n), dr((size_t)pairs * n);
@@ -56,8 +59,16 @@ static int batch_main(int pairs, int row, int col, int dispRange)
     }
     { void *w = nullptr; if (smt_malloc(&w, 256) == SMT_OK) smt_free(w); }
     auto t0 = std::chrono::steady_clock::now();
-    const int G = smt::AD_Census_batch_all_devices(L.data(), R.data(), pairs, dispRange, row, col, 10.0f, 30.0f, dl.data(), dr.data());
+    int G = 0;
+    double checksum = 0.0;
+    if (rccl) checksum = smt::AD_Census_batch_rccl(L.data(), R.data(), pairs, dispRange, row, col, 10.0f, 30.0f, dl.data(), dr.data(), &G);
+    else G = smt::AD_Census_batch_all_devices(L.data(), R.data(), pairs, dispRange, row, col, 10.0f, 30.0f, dl.data(), dr.data());
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rccl) {
+        double host_sum = 0.0;
+        for (size_t k = 0; k < (size_t)pairs * n; k++) host_sum += dl[k];
+        printf("checksum %.1f host_sum %.1f\n", checksum, host_sum);
+    }
     for (int b = 0; b < pairs; b++)
         printf("pair %d wta_left %016llx wta_right %016llx\n", b, (unsigned long long)fnv(&dl[b * n], n * 4),
                (unsigned long long)fnv(&dr[b * n], n * 4));
@@ -75,6 +86,7 @@ int main(int argc, char **argv)
     const bool from_files = argc > 4 && !strcmp(argv[1], "--images");
     try {
         if (argc > 5 && !strcmp(argv[1], "--batch")) return batch_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]));
+        if (argc > 5 && !strcmp(argv[1], "--batch-rccl")) return batch_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), true);
         std::vector<unsigned char> leftGray, rightGray;
         if (from_files) {
             // main.cpp:16-20: imread (3-channel BGR) + cvtColor(CV_BGR2GRAY)

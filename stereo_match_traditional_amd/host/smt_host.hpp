@@ -517,4 +517,93 @@ inline int AD_Census_batch_all_devices(const float *L, const float *R, int pairs
     return G;
 }
 
+#ifdef SMT_HOST_WITH_RCCL
+}  // namespace smt
+#include <rccl/rccl.h>
+namespace smt {
+// ------------------------------------------------------------------ config 5 with the exchange over RCCL / xGMI
+// Same sharding as AD_Census_batch_all_devices, but the disparity maps stay on the devices and are exchanged the
+// way SURVEY 8e prescribes: one ncclAllGather of the (padded) per-device [count][row][col] maps -- every device
+// ends up with all `pairs` maps -- and one ncclAllReduce(sum) of a float64 checksum.  Single process, one
+// communicator per device (ncclCommInitAll), group calls.  Returns the all-reduced checksum; gathered maps are
+// copied back from device 0.  Pairs are independent, so this is the only traffic between devices.
+inline void rccl_check(ncclResult_t r, const char *what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+inline double AD_Census_batch_rccl(const float *L, const float *R, int pairs, int dispRange, int row, int col, float sigmaC,
+                                   float sigmaS, float *dispL, float *dispR, int *devices_used = nullptr, int max_devices = 0)
+{
+    int G = 0;
+    check(smt_device_count(&G), "smt_device_count");
+    if (max_devices > 0 && G > max_devices) G = max_devices;
+    if (G > pairs) G = pairs;
+    if (G <= 0) throw std::runtime_error("no device / empty batch");
+    const size_t n = (size_t)row * col;
+    const int q = pairs / G, r = pairs % G, cmax = q + (r ? 1 : 0);
+    struct Dev {
+        smt_adcensus *h = nullptr; void *stream = nullptr;
+        float *L = nullptr, *R = nullptr, *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+        double *sum = nullptr; int start = 0, count = 0;
+    };
+    std::vector<Dev> dev(G);
+    std::vector<int> ids(G);
+    for (int g = 0; g < G; g++) ids[g] = g;
+    std::vector<ncclComm_t> comm(G);
+    rccl_check(ncclCommInitAll(comm.data(), G, ids.data()), "ncclCommInitAll");
+    for (int g = 0; g < G; g++) {
+        Dev &d = dev[g];
+        d.count = q + (g < r ? 1 : 0);
+        d.start = g * q + (g < r ? g : r);
+        check(smt_set_device(g), "smt_set_device");
+        check(smt_adcensus_create_on(g, row, col, dispRange, sigmaC, sigmaS, &d.h), "smt_adcensus_create_on");
+        check(smt_stream_create(&d.stream), "smt_stream_create");
+        check(smt_adcensus_set_stream(d.h, d.stream), "smt_adcensus_set_stream");
+        const size_t bytes = (size_t)d.count * n * sizeof(float), pad = (size_t)cmax * n * sizeof(float);
+        check(smt_malloc((void **)&d.L, bytes), "smt_malloc"); check(smt_malloc((void **)&d.R, bytes), "smt_malloc");
+        for (int v = 0; v < 2; v++) {
+            check(smt_malloc((void **)&d.send[v], pad), "smt_malloc");
+            check(smt_malloc((void **)&d.recv[v], pad * G), "smt_malloc");
+            check(smt_memset(d.send[v], 0, pad, d.stream), "smt_memset");       // shards are padded to the largest count
+        }
+        check(smt_malloc((void **)&d.sum, sizeof(double)), "smt_malloc");
+        check(smt_memcpy_h2d(d.L, L + (size_t)d.start * n, bytes, d.stream), "h2d");
+        check(smt_memcpy_h2d(d.R, R + (size_t)d.start * n, bytes, d.stream), "h2d");
+        check(smt_adcensus_compute_batch(d.h, d.L, d.R, d.count, SMT_VIEW_BOTH, d.send[0], d.send[1]), "smt_adcensus_compute_batch");
+        check(smt_sum_f32(d.send[0], (size_t)d.count * n, d.sum, d.stream), "smt_sum_f32");
+    }
+    // the exchange: both views' maps and the checksum, one group
+    rccl_check(ncclGroupStart(), "ncclGroupStart");
+    for (int g = 0; g < G; g++) {
+        Dev &d = dev[g];
+        for (int v = 0; v < 2; v++)
+            rccl_check(ncclAllGather(d.send[v], d.recv[v], (size_t)cmax * n, ncclFloat, comm[g], (hipStream_t)d.stream), "ncclAllGather");
+        rccl_check(ncclAllReduce(d.sum, d.sum, 1, ncclDouble, ncclSum, comm[g], (hipStream_t)d.stream), "ncclAllReduce");
+    }
+    rccl_check(ncclGroupEnd(), "ncclGroupEnd");
+    // device 0 holds everything: trim the padding while copying back
+    double checksum = 0.0;
+    check(smt_set_device(0), "smt_set_device");
+    for (int g = 0; g < G; g++) {
+        const size_t bytes = (size_t)dev[g].count * n * sizeof(float);
+        check(smt_memcpy_d2h(dispL + (size_t)dev[g].start * n, dev[0].recv[0] + (size_t)g * cmax * n, bytes, dev[0].stream), "d2h");
+        check(smt_memcpy_d2h(dispR + (size_t)dev[g].start * n, dev[0].recv[1] + (size_t)g * cmax * n, bytes, dev[0].stream), "d2h");
+    }
+    check(smt_memcpy_d2h(&checksum, dev[0].sum, sizeof(double), dev[0].stream), "d2h");
+    for (int g = 0; g < G; g++) {
+        Dev &d = dev[g];
+        check(smt_set_device(g), "smt_set_device");
+        check(smt_adcensus_status(d.h), "smt_adcensus_status");        // synchronises the device's stream
+        smt_free(d.L); smt_free(d.R); smt_free(d.sum);
+        for (int v = 0; v < 2; v++) { smt_free(d.send[v]); smt_free(d.recv[v]); }
+        smt_adcensus_destroy(d.h);
+        smt_stream_destroy(d.stream);
+        ncclCommDestroy(comm[g]);
+    }
+    check(smt_set_device(0), "smt_set_device");
+    if (devices_used) *devices_used = G;
+    return checksum;
+}
+#endif  // SMT_HOST_WITH_RCCL
+
 }  // namespace smt

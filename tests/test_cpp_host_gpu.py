@@ -82,7 +82,8 @@ def test_main_cpp_counterpart_from_image_files(smt, O, tmp_path):
     lr, cls, no, nm = O.lrcheck(dl, dr, 2)
     assert got["cost_left"] == f"{O.fnv1a(cl):016x}" and got["lr_left"] == f"{O.fnv1a(lr):016x}"
     shown = smt.imread(tmp_path / "d.png", 0)
-    exp = np.where(np.isfinite(lr), (lr * 255.0 / (D - 1) + 0.5).astype(np.uint8), 0).astype(np.uint8)
+    fin = np.isfinite(lr)
+    exp = np.where(fin, (np.where(fin, lr, 0.0) * 255.0 / (D - 1) + 0.5).astype(np.uint8), 0).astype(np.uint8)
     assert np.array_equal(shown, exp)
 
 
@@ -95,6 +96,24 @@ def test_batch_over_all_visible_devices(smt, O):
     lines = [l.split() for l in r.stdout.strip().splitlines()]
     assert len(lines) == P
     for b, l in enumerate(lines):
+        Lg, Rg = O.synth_pair(H, W, D, 1000 + b)
+        assert l[3] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 0))):016x}", b
+        assert l[5] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 1))):016x}", b
+
+
+def test_batch_with_rccl_exchange(smt, O):
+    """host/smt_host.hpp AD_Census_batch_rccl: the batched configuration with the maps exchanged by ncclAllGather
+    and a float64 checksum ncclAllReduce (RCCL; single process, one communicator per visible device -- one here):
+    every gathered map against the oracle, the all-reduced checksum against the host sum of the left maps."""
+    H, W, D, P = 40, 100, 64, 5
+    r = subprocess.run([EXE, "--batch-rccl", str(P), str(H), str(W), str(D)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    chk = [l for l in lines if l[0] == "checksum"][0]
+    assert float(chk[1]) == float(chk[3]) and float(chk[1]) > 0
+    maps = [l for l in lines if l[0] == "pair"]
+    assert len(maps) == P
+    for b, l in enumerate(maps):
         Lg, Rg = O.synth_pair(H, W, D, 1000 + b)
         assert l[3] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 0))):016x}", b
         assert l[5] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 1))):016x}", b
