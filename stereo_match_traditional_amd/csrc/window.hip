@@ -321,7 +321,11 @@ __global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, con
 //     16 + D - 1 window positions per row.  Per window row the workgroup builds that table once in LDS
 //     (T[column][xs], float64) and every lane reads its entry with one linear, conflict-free ds_read_b64 --
 //     no |difference|, no table-address arithmetic, no random LDS access in the tap loop.
-// What is left per tap and slot: byte extract, |pa - pb|, min T, int -> f64, one multiply, two FMAs.
+//   * the other image's byte behind a tap depends on xs + column only: the row is staged once per window row as
+//     floats in LDS (P[xs + c]); the truncated error min(|pa - pb|, T) is then two f32 instructions on exact
+//     small integers (subtract, min with |.| modifier) and one f32 -> f64 conversion -- no byte extraction, no
+//     global loads in the tap loop, and no integer -> f64 conversion (half rate on this part).
+// What is left per tap and slot: f32 subtract, f32 min |.|, f32 -> f64, one multiply, two FMAs.
 // Arithmetic and summation order are those of k_asw (and the results identical bit for bit): the table
 // holds the same float64 products w0*space^2, and sw / sv accumulate the taps in the same order.
 constexpr int A3P = 16;                                   // pixels (waves) per workgroup
@@ -335,7 +339,8 @@ __global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ 
     const int side = 2 * wins + 1, Wp = W + 2 * wins, Hp = H + 2 * wins;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // one dword per anchor pixel (scalar / uniform loads want 4-byte elements)
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Hp * Wp; k += (size_t)gridDim.x * 256) a32[k] = Ap[k];
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Hp * Wp; k += (size_t)gridDim.x * 256)
+        a32[k] = __float_as_uint((float)Ap[k]);           // as float: the truncated error is formed in f32 (exact small integers)
     const size_t p = (size_t)blockIdx.x * 4 + wv;
     if (p >= (size_t)H * W) return;
     const int io = (int)(p / W), jo = (int)(p % W);
@@ -364,7 +369,7 @@ __global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ L
     constexpr int NXP = A3P + 64 * K;                      // window positions of the other image per row (padded)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int side = 2 * wins + 1, Wp = W + 2 * wins;
-    double *s_T = (double *)smem;                          // [side][NXP]
+    double *s_T = (double *)smem;                          // [NXP][side]
     double *s_color = s_T + (size_t)side * NXP;            // [256]
     for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
 
@@ -383,19 +388,19 @@ __global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ L
     const unsigned *arow = a32 + (size_t)io * Wp + jc;
 
     double sw[K], sv[K];
-    unsigned xo[K];                                        // window position of slot k in the other image's row
     const double *tk[K];
+    const float *pk[K];
+    float *s_P = (float *)(s_color + 256);                 // [NXP + side]: the other image's current window row as floats
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int d = lane + 64 * k;
         const int dd = d < dmax ? d : (dmax < 0 ? 0 : dmax);   // d >= D lanes compute a harmless duplicate
         const int xs = (view == 0) ? jc - dd : jc + dd;
-        xo[k] = (unsigned)xs;
-        tk[k] = s_T + (xs - xbase);
+        tk[k] = s_T + (size_t)(xs - xbase) * side;        // row e of T[e][c]: the row stride (side, odd) keeps b64 reads conflict-free
+        pk[k] = s_P + (xs - xbase);
         sw[k] = 0.0; sv[k] = 0.0;
     }
-    const int nfull = side >> 2, ctail = side - 4;
-    const bool has_tail = (side & 3) != 0;
+    const float Tf = (float)T;
     // table builders: thread t owns the window position e = t % NXP and the columns t / NXP, + ngrp, ...; its
     // centre byte does not depend on the window row
     constexpr int NGRP = (A3P * 64) / NXP;
@@ -405,47 +410,40 @@ __global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ L
     const unsigned tcb = Bimg[(size_t)wins * Wp + tx + wins];
 
     for (int r = 0; r < side; r++) {
-        __syncthreads();                                   // previous row's table is no longer read (and s_color is in)
-        // T[c][e] = color[|B[r][x + c] - B[wins][x + wins]|] for the window position x = xbase + e
+        __syncthreads();                                   // previous row's tables are no longer read (and s_color is in)
+        // T[e][c] = color[|B[r][x + c] - B[wins][x + wins]|] for the window position x = xbase + e;
+        // P[xx] = (float)B[r][xbase + xx]: the byte behind tap column c of window position e sits at xx = e + c
         if (tg < NGRP) {
             const uint8_t *brow = Bimg + (size_t)r * Wp + tx;
             for (int c = tg; c < side; c += NGRP)
-                s_T[c * NXP + te] = s_color[__builtin_amdgcn_sad_u16((unsigned)brow[c], tcb, 0u)];
+                s_T[te * side + c] = s_color[__builtin_amdgcn_sad_u16((unsigned)brow[c], tcb, 0u)];
+        }
+        if ((int)threadIdx.x < NXP + side) {
+            int x = xbase + (int)threadIdx.x;
+            x = x < 0 ? 0 : (x > Wp - 1 ? Wp - 1 : x);
+            s_P[threadIdx.x] = (float)Bimg[(size_t)r * Wp + x];
         }
         __syncthreads();
-        auto taps4 = [&](const unsigned (&word)[K], int c0, int keep_from) {
+        const double *wr = wrow + r * side;                // wave-uniform operands through the scalar cache
+        const unsigned *ar = arow + (size_t)r * Wp;
+        auto tap = [&](int c) {
+            const double w = wr[c];
+            const float pa = __uint_as_float(ar[c]);
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) {
-                const int c = c0 + cc;
-                // wave-uniform operands through the scalar cache
-                double w = wrow[r * side + c];
-                const unsigned pa = arow[(size_t)r * Wp + c];
-                if (c < keep_from) w = 0.0;                // tail dword: columns already counted get weight 0
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const unsigned pb = (word[k] >> (8 * cc)) & 0xffu;
-                    const double c1 = tk[k][(size_t)c * NXP];
-                    unsigned e = __builtin_amdgcn_sad_u16(pa, pb, 0u);
-                    e = e > (unsigned)T ? (unsigned)T : e;
-                    const double m2 = w * c1;
-                    sw[k] = __builtin_fma(w, c1, sw[k]);
-                    sv[k] = __builtin_fma(m2, (double)e, sv[k]);
-                }
+            for (int k = 0; k < K; k++) {
+                const double c1 = tk[k][c];
+                const float e = fminf(fabsf(pa - pk[k][c]), Tf);   // min(|pa - pb|, T), exact in f32
+                const double m2 = w * c1;
+                sw[k] = __builtin_fma(w, c1, sw[k]);
+                sv[k] = __builtin_fma(m2, (double)e, sv[k]);
             }
         };
-        const uint8_t *brow = Bimg + (size_t)r * Wp;       // uniform row base + per-lane 32-bit position
-        for (int g = 0; g < nfull; g++) {
-            unsigned word[K];
+        int c = 0;
+        for (; c + 8 <= side; c += 8) {
 #pragma unroll
-            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], brow + 4 * g + xo[k], 4);
-            taps4(word, 4 * g, 0);
+            for (int cc = 0; cc < 8; cc++) tap(c + cc);
         }
-        if (has_tail) {
-            unsigned word[K];
-#pragma unroll
-            for (int k = 0; k < K; k++) __builtin_memcpy(&word[k], brow + ctail + xo[k], 4);
-            taps4(word, ctail, 4 * nfull);
-        }
+        for (; c < side; c++) tap(c);
     }
     if (!live) return;
     float cv[K];
@@ -532,7 +530,7 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     const int v = view == SMT_VIEW_LEFT ? 0 : 1;
     if (g_asw_impl == 3 && side >= 5) {
         const int K = (D + 63) / 64, NXP = A3P + 64 * K;
-        const size_t shm3 = ((size_t)side * NXP + 256) * 8;
+        const size_t shm3 = ((size_t)side * NXP + 256) * 8 + (size_t)(NXP + side) * 4;
         const size_t nt = (size_t)N * side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
         hipStream_t st = smt_stream(stream);
         double *w0 = nullptr;
