@@ -475,9 +475,10 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
             const double *space, const double *color, int T, int view, float *disp, float *cost,
             void *stream);
 /* Test hook (process-wide): 3 = anchor-weight table + per-row other-image weight tables in LDS (default; needs
- * H*W*(2*winSize+3)^2*8 bytes of scratch device memory for the duration of the call, stream-ordered),
+ * H*W*(2*winSize+3)^2*8 bytes of scratch device memory for the duration of the call, stream-ordered; a wave
+ * carries two pixels), 4 = the same with one pixel per wave,
  * 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
- * Both produce identical bits. */
+ * All produce identical bits. */
 int smt_asw_set_impl(int impl);
 /* CrossCheckDiaparity (ASW.h:108-145): float maps -> uint8 map, 0 = rejected. */
 int smt_asw_crosscheck(const float *dispL, const float *dispR, int H, int W, uint8_t *out,

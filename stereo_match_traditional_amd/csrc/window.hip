@@ -317,15 +317,23 @@ __global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, con
 //     dword-per-pixel copy of the anchor image; the main kernel reads both through the SCALAR cache
 //     (uniform addresses, s_load), which costs no vector issue slot at all;
 //   * the other image's weight color[|B(q) - B(centre)|] depends only on the window position in the other
-//     image, xs = j -+ d, not on (j, d) separately: the 16 pixels of a workgroup x D hypotheses touch only
-//     16 + D - 1 window positions per row.  Per window row the workgroup builds that table once in LDS
-//     (T[column][xs], float64) and every lane reads its entry with one linear, conflict-free ds_read_b64 --
-//     no |difference|, no table-address arithmetic, no random LDS access in the tap loop.
+//     image, xs = j -+ d, not on (j, d) separately: the 32 pixels of a workgroup (16 waves x 2 pixels) x D
+//     hypotheses touch only 32 + D - 1 window positions per row.  Per window row the workgroup builds that
+//     table once in LDS (T[xs][column], float64, odd row stride) and every lane reads its entry with one
+//     conflict-free ds_read_b64 -- no |difference|, no table-address arithmetic, no random LDS access in the
+//     tap loop.  The reads go through lds_f64(): left alone the compiler pairs neighbouring columns into
+//     ds_read2_b64, which the LDS serves at half the bytes per clock.
 //   * the other image's byte behind a tap depends on xs + column only: the row is staged once per window row as
 //     floats in LDS (P[xs + c]); the truncated error min(|pa - pb|, T) is then two f32 instructions on exact
-//     small integers (subtract, min with |.| modifier) and one f32 -> f64 conversion -- no byte extraction, no
-//     global loads in the tap loop, and no integer -> f64 conversion (half rate on this part).
-// What is left per tap and slot: f32 subtract, f32 min |.|, f32 -> f64, one multiply, two FMAs.
+//     small integers (subtract, min with |.| modifier) and one f32 -> f64 conversion -- no byte extraction and
+//     no global loads in the tap loop.
+// What is left per tap and slot: f32 subtract, f32 min |.|, f32 -> f64, one multiply, two FMAs -- 6 vector
+// instructions, 7.0 measured with the table build and the address updates (rocprofv3 SQ_INSTS_VALU), on a
+// VALU that is busy 93 % of the kernel's cycles (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)).
+// Issue rates measured with tools/valu_rate.hip (16 waves per SIMD, ns per wave64 instruction per SIMD): every
+// f64 instruction used here (fma, mul, add, min, cvt_f64_f32) 1.71-1.74 ns = 4 cycles; v_sub_f32 0.90 ns = 2 cycles;
+// v_min_f32 with |.| (VOP3) 4 cycles.  Forming the error in f64 from a float64 copy of the row (add + min, one
+// instruction less) was tried and measured equal (17.97 against 17.74 ms): more LDS bytes per tap, nothing gained.
 // Arithmetic and summation order are those of k_asw (and the results identical bit for bit): the table
 // holds the same float64 products w0*space^2, and sw / sv accumulate the taps in the same order.
 constexpr int A3P = 16;                                   // pixels (waves) per workgroup
@@ -360,45 +368,73 @@ __global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ 
     }
 }
 
-template <int K>
-__global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+// One ds_read_b64 that stays one: the compiler would pair neighbouring columns into ds_read2_b64, which the LDS
+// serves at half the bytes per clock of ds_read_b64 (MI355X_MICROARCH.md, LDS table).
+__device__ __forceinline__ double lds_f64(const double *p)
+{
+    return *(const volatile __attribute__((address_space(3))) double *)p;
+}
+
+// A pointer the compiler must treat as wave-uniform (its loads then go through the scalar cache).
+template <class P>
+__device__ __forceinline__ P uniform_ptr(P p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (P)(((uint64_t)hi << 32) | lo);
+}
+
+// A3Q = pixels per wave: the per-row tables are built once for A3P * A3Q pixels
+template <int K, int A3Q>
+__global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
                                                    int W, int D, int wins, const double *__restrict__ color,
                                                    const double *__restrict__ w0, const unsigned *__restrict__ a32, int T,
                                                    int view, float *__restrict__ disp, float *__restrict__ cost_out)
 {
-    constexpr int NXP = A3P + 64 * K;                      // window positions of the other image per row (padded)
+    constexpr int NPX = A3P * A3Q;                         // pixels per workgroup
+    constexpr int NXP = NPX + 64 * K;                      // window positions of the other image per row (padded)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int side = 2 * wins + 1, Wp = W + 2 * wins;
     double *s_T = (double *)smem;                          // [NXP][side]
     double *s_color = s_T + (size_t)side * NXP;            // [256]
+    float *s_P = (float *)(s_color + 256);                 // [NXP + side]: the other image's current window row as floats
     for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int io = blockIdx.y, jo0 = blockIdx.x * A3P;
-    const int jo = jo0 + wv;
-    const bool live = jo < W;                              // waves past the row end still help to build the tables
-    const int jc = live ? jo : W - 1;
+    const int io = blockIdx.y, jo0 = blockIdx.x * NPX;
     // the other image and the first window position the workgroup can touch:
-    //   view 0: xs = jo - dd in [jo0 - (D-1), jo0 + 15];   view 1: xs = jo + dd in [jo0, jo0 + 15 + D-1]
+    //   view 0: xs = jo - dd in [jo0 - (D-1), jo0 + NPX-1];   view 1: xs = jo + dd in [jo0, jo0 + NPX-1 + D-1]
     const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
     const int xbase = (view == 0) ? jo0 - (64 * K - 1) : jo0;
-    const int dmax = (view == 0) ? jc : (W - wins - 2 - jc);   // last in-range disparity (ASW.h:348 / :401)
-    const double *wrow = w0 + ((size_t)io * W + jc) * side * side;
-    const unsigned *arow = a32 + (size_t)io * Wp + jc;
 
-    double sw[K], sv[K];
-    const double *tk[K];
-    const float *pk[K];
-    float *s_P = (float *)(s_color + 256);                 // [NXP + side]: the other image's current window row as floats
+    // the wave's A3Q pixels: jo0 + wv and jo0 + A3P + wv (pixels past the row end still help to build the tables)
+    bool live[A3Q];
+    int jo[A3Q], dmax[A3Q];
+    typedef const __attribute__((address_space(4))) double *cdouble_p;     // constant address space: uniform loads become s_load
+    typedef const __attribute__((address_space(4))) unsigned *cunsigned_p;
+    cdouble_p wrow[A3Q];
+    cunsigned_p arow[A3Q];
+    double sw[A3Q][K], sv[A3Q][K];
+    const double *tk[A3Q][K];
+    const float *pk[A3Q][K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int d = lane + 64 * k;
-        const int dd = d < dmax ? d : (dmax < 0 ? 0 : dmax);   // d >= D lanes compute a harmless duplicate
-        const int xs = (view == 0) ? jc - dd : jc + dd;
-        tk[k] = s_T + (size_t)(xs - xbase) * side;        // row e of T[e][c]: the row stride (side, odd) keeps b64 reads conflict-free
-        pk[k] = s_P + (xs - xbase);
-        sw[k] = 0.0; sv[k] = 0.0;
+    for (int q = 0; q < A3Q; q++) {
+        jo[q] = jo0 + q * A3P + wv;
+        live[q] = jo[q] < W;
+        const int jc = live[q] ? jo[q] : W - 1;
+        dmax[q] = (view == 0) ? jc : (W - wins - 2 - jc);  // last in-range disparity (ASW.h:348 / :401)
+        wrow[q] = (cdouble_p)(w0 + ((size_t)io * W + jc) * side * side);
+        arow[q] = (cunsigned_p)(a32 + (size_t)io * Wp + jc);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int d = lane + 64 * k;
+            const int dd = d < dmax[q] ? d : (dmax[q] < 0 ? 0 : dmax[q]);   // d >= D lanes compute a harmless duplicate
+            const int xs = (view == 0) ? jc - dd : jc + dd;
+            tk[q][k] = s_T + (size_t)(xs - xbase) * side;  // row e of T[e][c]: the row stride (side, odd) keeps b64 reads conflict-free
+            pk[q][k] = s_P + (xs - xbase);
+            sw[q][k] = 0.0; sv[q][k] = 0.0;
+        }
     }
     const float Tf = (float)T;
     // table builders: thread t owns the window position e = t % NXP and the columns t / NXP, + ngrp, ...; its
@@ -424,58 +460,64 @@ __global__ void __launch_bounds__(A3P * 64) k_asw3(const uint8_t *__restrict__ L
             s_P[threadIdx.x] = (float)Bimg[(size_t)r * Wp + x];
         }
         __syncthreads();
-        const double *wr = wrow + r * side;                // wave-uniform operands through the scalar cache
-        const unsigned *ar = arow + (size_t)r * Wp;
-        auto tap = [&](int c) {
-            const double w = wr[c];
-            const float pa = __uint_as_float(ar[c]);
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const double c1 = tk[k][c];
-                const float e = fminf(fabsf(pa - pk[k][c]), Tf);   // min(|pa - pb|, T), exact in f32
-                const double m2 = w * c1;
-                sw[k] = __builtin_fma(w, c1, sw[k]);
-                sv[k] = __builtin_fma(m2, (double)e, sv[k]);
+        for (int q = 0; q < A3Q; q++) {
+            cdouble_p wr = uniform_ptr(wrow[q] + r * side);   // wave-uniform operands through the scalar cache
+            cunsigned_p ar = uniform_ptr(arow[q] + (size_t)r * Wp);
+            auto tap = [&](int c) {
+                const double w = wr[c];
+                const float pa = __uint_as_float(ar[c]);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const double c1 = lds_f64(tk[q][k] + c);
+                    const float e = fminf(fabsf(pa - pk[q][k][c]), Tf);   // min(|pa - pb|, T), exact in f32
+                    const double m2 = w * c1;
+                    sw[q][k] = __builtin_fma(w, c1, sw[q][k]);
+                    sv[q][k] = __builtin_fma(m2, (double)e, sv[q][k]);
+                }
+            };
+            int c = 0;
+            for (; c + 8 <= side; c += 8) {
+#pragma unroll
+                for (int cc = 0; cc < 8; cc++) tap(c + cc);
             }
-        };
-        int c = 0;
-        for (; c + 8 <= side; c += 8) {
-#pragma unroll
-            for (int cc = 0; cc < 8; cc++) tap(c + cc);
+            for (; c < side; c++) tap(c);
         }
-        for (; c < side; c++) tap(c);
     }
-    if (!live) return;
-    float cv[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) cv[k] = (float)(sv[k] / sw[k]);
-    // WinTakeAll: first strict minimum (:193-208); dmax < 0: see k_asw
-    float lm = INFINITY; int ld = 0;
+    for (int q = 0; q < A3Q; q++) {
+        if (!live[q]) continue;
+        float cv[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int d = lane + 64 * k;
-        if (d < D && lm > cv[k]) { lm = cv[k]; ld = d; }
-    }
-    const float m = wave_min_f32(lm);
-    int cand = (lm == m) ? ld : 0x7fffffff;
-    for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
-    const size_t p = (size_t)io * W + jo;
-    if (lane == 0) disp[p] = (dmax < 0) ? 0.0f : (float)cand;
-    if (cost_out) {
+        for (int k = 0; k < K; k++) cv[k] = (float)(sv[q][k] / sw[q][k]);
+        // WinTakeAll: first strict minimum (:193-208); dmax < 0: see k_asw
+        float lm = INFINITY; int ld = 0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int d = lane + 64 * k;
-            if (d < D) cost_out[p * D + d] = (dmax < 0) ? NAN : cv[k];
+            if (d < D && lm > cv[k]) { lm = cv[k]; ld = d; }
+        }
+        const float m = wave_min_f32(lm);
+        int cand = (lm == m) ? ld : 0x7fffffff;
+        for (int off = 32; off >= 1; off >>= 1) cand = min(cand, __shfl_xor(cand, off, WAVE));
+        const size_t p = (size_t)io * W + jo[q];
+        if (lane == 0) disp[p] = (dmax[q] < 0) ? 0.0f : (float)cand;
+        if (cost_out) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int d = lane + 64 * k;
+                if (d < D) cost_out[p * D + d] = (dmax[q] < 0) ? NAN : cv[k];
+            }
         }
     }
 }
 
 }  // namespace
 
-static int g_asw_impl = 3;                               // 3: k_asw_anchor + k_asw3 (default); 1: k_asw (first formulation)
+static int g_asw_impl = 3;   // 3: k_asw_anchor + k_asw3, two pixels per wave (default); 4: one pixel per wave; 1: k_asw (first formulation)
 SMT_API int smt_asw_set_impl(int impl)
 {
-    if (impl != 1 && impl != 3) return SMT_ERR_ARG;
+    if (impl != 1 && impl != 3 && impl != 4) return SMT_ERR_ARG;
     g_asw_impl = impl;
     return SMT_OK;
 }
@@ -528,8 +570,9 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     if (side > 64) return SMT_ERR_ARG;                   // one window row per wave pass
     const int N = H * W;
     const int v = view == SMT_VIEW_LEFT ? 0 : 1;
-    if (g_asw_impl == 3 && side >= 5) {
-        const int K = (D + 63) / 64, NXP = A3P + 64 * K;
+    if (g_asw_impl >= 3 && side >= 5) {
+        const int A3Q = g_asw_impl == 4 ? 1 : 2;
+        const int K = (D + 63) / 64, NXP = A3P * A3Q + 64 * K;
         const size_t shm3 = ((size_t)side * NXP + 256) * 8 + (size_t)(NXP + side) * 4;
         const size_t nt = (size_t)N * side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
         hipStream_t st = smt_stream(stream);
@@ -551,11 +594,16 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
             if (hipMallocAsync((void **)&a32, na * 4, st) != hipSuccess) { (void)hipFreeAsync(w0, st); return SMT_ERR_ALLOC; }
             const uint8_t *Ap = v == 0 ? Lp : Rp;
             hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32);
-            const dim3 grid((W + A3P - 1) / A3P, H);
+            const dim3 grid((W + A3P * A3Q - 1) / (A3P * A3Q), H);
 #define SMT_ASW3(KK)                                                                                         \
     do {                                                                                                     \
-        SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
-        hipLaunchKernelGGL(k_asw3<KK>, grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+        if (A3Q == 2) {                                                                                      \
+            SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
+            hipLaunchKernelGGL((k_asw3<KK, 2>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+        } else {                                                                                             \
+            SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
+            hipLaunchKernelGGL((k_asw3<KK, 1>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+        }                                                                                                    \
     } while (0)
             switch (K) {
             case 1: SMT_ASW3(1); break;

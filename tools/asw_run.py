@@ -10,6 +10,8 @@ L, R = synth.synth_pair(H, W, D, 4)
 Lp = torch.from_numpy(np.pad(L, ws + 1, mode="edge")).to(DEV)
 Rp = torch.from_numpy(np.pad(R, ws + 1, mode="edge")).to(DEV)
 sp, cm = smt.asw_masks(ws, 50.0, 30.0, DEV)
+if len(sys.argv) > 2:
+    smt.asw_set_impl(int(sys.argv[2]))
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     d = smt.AdaptiveSupportWeight(Lp, Rp, ws, D, sp, cm, 40)
 torch.cuda.synchronize()
