@@ -639,7 +639,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
 template <int C, int ORDER, bool FULL, int QR, int SKIP>
-__global__ void __launch_bounds__(NT, 6) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
