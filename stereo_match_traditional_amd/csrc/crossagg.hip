@@ -9,34 +9,63 @@
 // (t = -arm .. +arm).  Pass 1 goes cur -> tmp, pass 2 tmp -> cur with the division by the
 // uint16 support count, exactly like vec_cost_tmp_[0/1] and cost_aggr_ per plane.
 #include "smt_common.h"
+#include <type_traits>
 #include <new>
 
 namespace {
 
 constexpr int NT = 256;
 
-__device__ __forceinline__ int col_dist(const uint8_t *a, const uint8_t *b)
+// one pixel's B, G, R as the low three bytes of a word: one (unaligned) dword load instead of three byte loads --
+// the walk is bound by the number of load instructions.  The last pixel of the image is read byte by byte (the
+// dword would reach one byte past the buffer).
+typedef uint32_t __attribute__((aligned(1))) ca_u32_unaligned;
+__device__ __forceinline__ uint32_t ca_pixel(const uint8_t *img, size_t p, size_t last)
 {
-    const int d0 = abs((int)a[0] - (int)b[0]), d1 = abs((int)a[1] - (int)b[1]), d2 = abs((int)a[2] - (int)b[2]);
+    const uint8_t *q = img + p * 3;
+    if (p == last) return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+    return *reinterpret_cast<const ca_u32_unaligned *>(q) & 0xffffffu;
+}
+
+__device__ __forceinline__ int col_dist(uint32_t a, uint32_t b)
+{
+    const int d0 = abs((int)(a & 255u) - (int)(b & 255u)), d1 = abs((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u)),
+              d2 = abs((int)(a >> 16) - (int)(b >> 16));
     return max(d0, max(d1, d2));                                          // ColorDist, h:78-80
 }
 
+// The walk's tests depend on the pixel n steps out, the one before it and the anchor -- never on an earlier
+// test -- so the pixels are fetched eight steps at a time with independent loads and the sequential rule is then
+// applied in registers (a load per step with the break deciding the next one costs a memory latency per step:
+// 120-150 us at 1280x720 against the few microseconds the loads themselves need).
 __device__ int ca_arm(const uint8_t *img, int W, int H, int x, int y, int dx, int dy, int L1, int L2,
                       int t1, int t2)
 {
-    const uint8_t *c0 = img + ((size_t)y * W + x) * 3;
-    const uint8_t *prev = c0;
+    const size_t last = (size_t)W * H - 1;
+    const uint32_t c0 = ca_pixel(img, (size_t)y * W + x, last);
+    uint32_t prev = c0;
     const int lim = L1 < 255 ? L1 : 255;                                  // MAX_ARM_LENGTH
-    int xn = x + dx, yn = y + dy, len = 0;
-    for (int n = 0; n < lim; n++) {
-        if (xn < 0 || xn == W || yn < 0 || yn == H) break;                // :154-163
-        const uint8_t *c = img + ((size_t)yn * W + xn) * 3;
-        const int d1 = col_dist(c, c0);
-        if (d1 >= t1) break;                                              // :169-172
-        if (n > 0 && col_dist(c, prev) >= t1) break;                      // :175-180
-        if (n + 1 > L2 && d1 >= t2) break;                                // :183-187
-        len++;
-        prev = c; xn += dx; yn += dy;
+    int len = 0;
+    for (int n0 = 0; n0 < lim; n0 += 8) {
+        uint32_t c[8];
+        bool in[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int xn = x + dx * (n0 + k + 1), yn = y + dy * (n0 + k + 1);
+            in[k] = n0 + k < lim && xn >= 0 && xn < W && yn >= 0 && yn < H;          // :154-163
+            c[k] = in[k] ? ca_pixel(img, (size_t)yn * W + xn, last) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int n = n0 + k;
+            if (!in[k]) return len;
+            const int d1 = col_dist(c[k], c0);
+            if (d1 >= t1) return len;                                     // :169-172
+            if (n > 0 && col_dist(c[k], prev) >= t1) return len;          // :175-180
+            if (n + 1 > L2 && d1 >= t2) return len;                       // :183-187
+            len++;
+            prev = c[k];
+        }
     }
     return len;
 }
@@ -44,15 +73,13 @@ __device__ int ca_arm(const uint8_t *img, int W, int H, int x, int y, int dx, in
 __global__ void __launch_bounds__(NT) k_ca_arms(const uint8_t *__restrict__ img, int W, int H, int L1, int L2,
                                                 int t1, int t2, uint8_t *__restrict__ arms)
 {
+    // blockIdx.y = direction: four times the threads, each with one walk of dependent byte loads instead of four
     const int p = blockIdx.x * NT + threadIdx.x;
     if (p >= W * H) return;
     const int y = p / W, x = p - y * W;
-    uchar4 a;
-    a.x = (uint8_t)ca_arm(img, W, H, x, y, -1, 0, L1, L2, t1, t2);
-    a.y = (uint8_t)ca_arm(img, W, H, x, y, +1, 0, L1, L2, t1, t2);
-    a.z = (uint8_t)ca_arm(img, W, H, x, y, 0, -1, L1, L2, t1, t2);
-    a.w = (uint8_t)ca_arm(img, W, H, x, y, 0, +1, L1, L2, t1, t2);
-    reinterpret_cast<uchar4 *>(arms)[p] = a;
+    const int dir = blockIdx.y;                             // 0 left, 1 right, 2 up, 3 down: the byte order of the map
+    const int dx = dir == 0 ? -1 : (dir == 1 ? 1 : 0), dy = dir == 2 ? -1 : (dir == 3 ? 1 : 0);
+    arms[(size_t)p * 4 + dir] = (uint8_t)ca_arm(img, W, H, x, y, dx, dy, L1, L2, t1, t2);
 }
 
 // cnt[0]: horizontal first (pass-1 = L+R+1, pass-2 sums those along the vertical arm);
@@ -117,8 +144,10 @@ __global__ void __launch_bounds__(NT) k_ca_pass(const float *__restrict__ src, f
 // and adds each tap to all 16 accumulators as fma(x, f, acc), f = 1.0f for the pixels whose interval holds it
 // and 0.0f for the others (fma(x, 1, acc) is the reference's acc + x, fma(x, 0, acc) is acc bit for bit for
 // finite x; a pixel whose result is NaN is recomputed by the plain walk, which is the reference's answer in every
-// case).  The membership of a tap is one ballot; its 16 flags are two rows of the 256 x 8 table; 4-pixel groups
-// without a member are skipped.  16 + a + b taps instead of 16 x (a + b + 1).
+// case).  The membership masks of 64 positions are built at once (lane = position); a tap's 16 flags are two rows
+// of the 256 x 8 table, fetched one tap ahead.  16 + a + b taps instead of 16 x (a + b + 1).
+// Measured at 1280x720x128 (profiles/r2f): non-final passes 0.19 ms = the time of reading and writing the volume
+// once; final passes (IEEE division per output) 0.25 ms.
 constexpr int CAP = 16;
 typedef float caf2 __attribute__((ext_vector_type(2)));
 typedef int cai2 __attribute__((ext_vector_type(2)));
@@ -132,7 +161,16 @@ __global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, 
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long wid = (long)blockIdx.x * (NT / 64) + wv;
+    // HORIZ: workgroups are dealt to the 8 XCDs round-robin, and the tiles of neighbouring workgroups share their
+    // halo taps; giving every XCD one contiguous range of workgroups (rows) keeps that sharing inside one L2
+    // (measured: 1.8x the input fetched across the fabric with the plain order).  The vertical pass already has
+    // its vertical neighbours on one XCD (W / 4 workgroups per band, a multiple of 8 for the usual widths).
+    long wg = blockIdx.x;
+    if (HORIZ) {
+        const long per = gridDim.x / 8;                     // gridDim.x is a multiple of 8 (host); surplus workgroups leave at y0 >= H
+        wg = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    const long wid = wg * (NT / 64) + wv;
     int x0, y0, npx;
     if (HORIZ) {
         const int nxb = (W + CAP - 1) / CAP;
@@ -186,33 +224,98 @@ __global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, 
             for (int k = 0; k < C; k++) x[k] = (dl + k < D) ? sp[k] : 0.0f;
         }
     };
-    auto add_flagged = [&](unsigned m, const float (&x)[C]) {
+    // Tap loop.  Taps are umin .. umax in increasing order; the tap pointer is wave-uniform and advances by one
+    // pixel step per tap (two scalar adds -- no per-tap 64-bit multiply); the 16 flags of a tap (two rows of the
+    // table) are fetched one tap AHEAD of the FMAs that use them into the other half of a two-deep SGPR buffer,
+    // so the scalar-cache latency sits behind the previous tap's FMAs (k_aggregate_multi, SKIP == 2).
+    typedef float caf8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) caf8 *cflag_p;
+    const cflag_p mtab = (cflag_p)(member);
+    auto load_flags = [&](unsigned m, caf8 (&F)[2]) {
+        F[0] = mtab[m & 255u];
+        F[1] = mtab[(m >> 8) & 255u];
+    };
+    auto fma_flagged = [&](unsigned m, const caf8 (&F)[2], const float (&x)[C]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const unsigned mb = (m >> (8 * h)) & 255u;
-            const float *f = member + mb * 8u;
             auto pair = [&](int j) {
-                const caf2 fl = caf2{f[2 * j], f[2 * j + 1]};
+                const caf2 fl = caf2{F[h][2 * j], F[h][2 * j + 1]};
 #pragma unroll
                 for (int c = 0; c < C; c++)
                     acc[4 * h + j][c] = __builtin_elementwise_fma(caf2{x[c], x[c]}, fl, acc[4 * h + j][c]);
             };
-            if (mb & 0x0fu) { pair(0); pair(1); }
-            if (mb & 0xf0u) { pair(2); pair(3); }
+            pair(0); pair(1); pair(2); pair(3);            // no group skip here: measured equal, and the skip's compares and branches load the scalar issue port
         }
     };
-    constexpr int G = 4;                                    // taps loaded ahead of their adds
-    for (int u0 = umin; u0 <= umax; u0 += G) {
-        unsigned m[G];
-        float x[G][C];
+    const long step = stride * D;                           // floats between two taps
+    typedef const __attribute__((address_space(1))) float *gfloat_p;
+    gfloat_p tp;                                            // wave-uniform tap pointer (global address space: no flat loads)
+    {
+        const uint64_t v = (uint64_t)(src + (p0 + (long)umin * stride) * D);
+        tp = (gfloat_p)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    }
+    // membership masks of the positions umin + lane and umin + 64 + lane (the union spans at most 16 + 2 * 34 + ...
+    // positions; longer arms take further chunks on the fly): bit q = pixel q's interval holds the position
+    auto chunk_masks = [&](int first) {
+        const int pos = first + lane;
+        unsigned mk = 0;
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const int u = min(u0 + k, umax);                // a short last group repeats its last tap with no member
-            m[k] = (u0 + k <= umax) ? (unsigned)__ballot(lo <= u && u <= hi) : 0u;
-            ld(p0 + u * stride, x[k]);
+        for (int q = 0; q < CAP; q++) {
+            const int lq = __builtin_amdgcn_readlane(lo, q), hq = __builtin_amdgcn_readlane(hi, q);
+            mk |= (lq <= pos && pos <= hq) ? (1u << q) : 0u;
         }
+        return mk;
+    };
+    unsigned maskv = chunk_masks(umin);
+    int mbase = umin;                                       // position of lane 0 of maskv
+    auto ldp = [&](gfloat_p base, float (&x)[C]) {
+        gfloat_p sp = base + dl;
+        if (FULL) {
+            if (C == 1) x[0] = sp[0];
+            else if (C == 2) { const cai2 v = *(const __attribute__((address_space(1))) cai2 *)(sp); x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y); }
+            else if (C == 3) {
+                x[0] = sp[0]; x[C > 1 ? 1 : 0] = sp[C > 1 ? 1 : 0]; x[C > 2 ? 2 : 0] = sp[C > 2 ? 2 : 0];
+            } else {
+                const cai4 v = *(const __attribute__((address_space(1))) cai4 *)(sp);
+                x[0] = __int_as_float(v.x); x[C > 1 ? 1 : 0] = __int_as_float(v.y);
+                x[C > 2 ? 2 : 0] = __int_as_float(v.z); x[C > 3 ? 3 : 0] = __int_as_float(v.w);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < G; k++) add_flagged(m[k], x[k]);
+            for (int k = 0; k < C; k++) x[k] = (dl + k < D) ? sp[k] : 0.0f;
+        }
+    };
+    auto group = [&](auto gtag, int u0) {
+        constexpr int GG = decltype(gtag)::value;
+        unsigned m[GG];
+        float x[GG][C];
+#pragma unroll
+        for (int k = 0; k < GG; k++) {
+            m[k] = (unsigned)__builtin_amdgcn_readlane((int)maskv, u0 + k - mbase);
+            ldp(tp, x[k]);
+            tp += step;
+        }
+        caf8 F[2][2];
+        load_flags(m[0], F[0]);
+#pragma unroll
+        for (int k = 0; k < GG; k++) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this tap's flags are in
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < GG) load_flags(m[k + 1], F[(k + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_flagged(m[k], F[k & 1], x[k]);
+        }
+    };
+    constexpr int G = C <= 2 ? 8 : 4;                       // taps loaded ahead of their adds (64 % G == 0: a group never straddles a mask chunk)
+    int u0 = umin;
+    while (u0 <= umax) {
+        const int uend = min(umax + 1, mbase + 64);         // taps of this mask chunk
+        for (; u0 + G <= uend; u0 += G) group(std::integral_constant<int, G>{}, u0);
+        if (G == 8 && u0 + 4 <= uend) { group(std::integral_constant<int, 4>{}, u0); u0 += 4; }
+        if (u0 + 2 <= uend) { group(std::integral_constant<int, 2>{}, u0); u0 += 2; }
+        if (u0 < uend) { group(std::integral_constant<int, 1>{}, u0); u0 += 1; }
+        if (u0 <= umax) { mbase += 64; maskv = chunk_masks(mbase); }
     }
     // finish: plain walk for pixels whose sum is NaN (a non-finite tap times a zero flag, or a genuine NaN)
 #pragma unroll
@@ -323,37 +426,39 @@ SMT_API int smt_crossagg_set_params(smt_crossagg *h, int L1, int L2, int t1, int
 }
 
 template <int C, bool FULL>
-static void ca_iter2(smt_crossagg *h, bool hfirst)
+static void ca_iter2(smt_crossagg *h, bool hfirst, const float *in)
 {
     const long nh = (long)h->H * ((h->W + CAP - 1) / CAP), nv = (long)h->W * ((h->H + CAP - 1) / CAP);   // waves per pass
-    dim3 gh((unsigned)((nh + 3) / 4)), gv((unsigned)((nv + 3) / 4));
+    dim3 gh((unsigned)(((nh + 3) / 4 + 7) / 8 * 8)), gv((unsigned)((nv + 3) / 4));   // gh: whole rounds of the 8 XCDs (k_ca_pass2's order)
     const uint16_t *cnt = h->cnt[hfirst ? 0 : 1];
     if (hfirst) {
-        hipLaunchKernelGGL((k_ca_pass2<C, true, false, FULL>), gh, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
+        hipLaunchKernelGGL((k_ca_pass2<C, true, false, FULL>), gh, dim3(NT), 0, h->stream, in, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
         hipLaunchKernelGGL((k_ca_pass2<C, false, true, FULL>), gv, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H, h->D, h->arms, cnt, h->member);
     } else {
-        hipLaunchKernelGGL((k_ca_pass2<C, false, false, FULL>), gv, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
+        hipLaunchKernelGGL((k_ca_pass2<C, false, false, FULL>), gv, dim3(NT), 0, h->stream, in, h->tmp, h->W, h->H, h->D, h->arms, cnt, h->member);
         hipLaunchKernelGGL((k_ca_pass2<C, true, true, FULL>), gh, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H, h->D, h->arms, cnt, h->member);
     }
 }
 
 template <int C>
-static void ca_iter(smt_crossagg *h, bool hfirst)
+// in: the volume the iteration starts from -- cost_init for the first one (cross_aggregator.cpp:108 copies it into
+// the working volume first; reading it in place saves that pass), h->cur afterwards
+static void ca_iter(smt_crossagg *h, bool hfirst, const float *in)
 {
     if (h->impl == 2) {
-        if (h->D == 64 * C) ca_iter2<C, true>(h, hfirst); else ca_iter2<C, false>(h, hfirst);
+        if (h->D == 64 * C) ca_iter2<C, true>(h, hfirst, in); else ca_iter2<C, false>(h, hfirst, in);
         return;
     }
     const int N = h->W * h->H;
     dim3 grid((N + 3) / 4);
     const uint16_t *cnt = h->cnt[hfirst ? 0 : 1];
     if (hfirst) {
-        hipLaunchKernelGGL((k_ca_pass<C, true, false>), grid, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H,
+        hipLaunchKernelGGL((k_ca_pass<C, true, false>), grid, dim3(NT), 0, h->stream, in, h->tmp, h->W, h->H,
                            h->D, h->arms, cnt);
         hipLaunchKernelGGL((k_ca_pass<C, false, true>), grid, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H,
                            h->D, h->arms, cnt);
     } else {
-        hipLaunchKernelGGL((k_ca_pass<C, false, false>), grid, dim3(NT), 0, h->stream, h->cur, h->tmp, h->W, h->H,
+        hipLaunchKernelGGL((k_ca_pass<C, false, false>), grid, dim3(NT), 0, h->stream, in, h->tmp, h->W, h->H,
                            h->D, h->arms, cnt);
         hipLaunchKernelGGL((k_ca_pass<C, true, true>), grid, dim3(NT), 0, h->stream, h->tmp, h->cur, h->W, h->H,
                            h->D, h->arms, cnt);
@@ -365,18 +470,20 @@ SMT_API int smt_crossagg_aggregate(smt_crossagg *h, const uint8_t *img, const fl
     if (!h || !img || !cost_init || iters < 0) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     const int N = h->W * h->H;
-    hipLaunchKernelGGL(k_ca_arms, dim3((N + NT - 1) / NT), dim3(NT), 0, h->stream, img, h->W, h->H, h->L1, h->L2,
+    hipLaunchKernelGGL(k_ca_arms, dim3((N + NT - 1) / NT, 4), dim3(NT), 0, h->stream, img, h->W, h->H, h->L1, h->L2,
                        h->t1, h->t2, h->arms);                            // BuildArms :76-86
     hipLaunchKernelGGL(k_ca_counts, dim3((N + NT - 1) / NT), dim3(NT), 0, h->stream, h->arms, h->W, h->H,
                        h->cnt[0], h->cnt[1]);                             // ComputeSupPixelCount
-    SMT_HIP(hipMemcpyAsync(h->cur, cost_init, (size_t)N * h->D * 4, hipMemcpyDeviceToDevice, h->stream)); // :108
+    if (iters == 0 && cost_init != h->cur)
+        SMT_HIP(hipMemcpyAsync(h->cur, cost_init, (size_t)N * h->D * 4, hipMemcpyDeviceToDevice, h->stream)); // :108
     bool hfirst = true;
     for (int k = 0; k < iters; k++) {                                     // :111-117
+        const float *in = k == 0 ? cost_init : h->cur;                    // first iteration: cost_init read in place
         switch ((h->D + 63) / 64) {
-        case 1: ca_iter<1>(h, hfirst); break;
-        case 2: ca_iter<2>(h, hfirst); break;
-        case 3: ca_iter<3>(h, hfirst); break;
-        default: ca_iter<4>(h, hfirst); break;
+        case 1: ca_iter<1>(h, hfirst, in); break;
+        case 2: ca_iter<2>(h, hfirst, in); break;
+        case 3: ca_iter<3>(h, hfirst, in); break;
+        default: ca_iter<4>(h, hfirst, in); break;
         }
         hfirst = !hfirst;
     }
