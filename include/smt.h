@@ -460,6 +460,11 @@ int smt_sad_crosscheck(const int32_t *dispL, const int32_t *dispR, int H, int W,
  * costs for tolerance checks. */
 int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int winSize, int32_t *disp,
             double *cost, void *stream);
+/* Test hook (process-wide): 2 = window statistics once per image + the cross term by v_dot4_u32_u8 (default for
+ * windows up to 31x31; needs 24*H*W bytes of stream-ordered scratch for the duration of the call), 1 = the
+ * reference's loop nest, one lane per hypothesis (also the fallback).  The two agree to ~1e-14 relative on the
+ * costs (both within the 1e-4 tolerance of the reference's own rounding) and give the same NaN pattern. */
+int smt_ncc_set_impl(int impl);
 
 /* getGausssianMask (ASW.h:16-35) and getColorMask (:41-47), computed on the HOST in
  * float64 exactly as the reference does.  space: (2*winSize+3)^2 doubles, color: 256. */

@@ -13,7 +13,7 @@ from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
 __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "costAggregationNew", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
-           "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "asw_masks",
+           "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "ncc_set_impl", "asw_masks",
            "AdaptiveSupportWeight", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
            "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline"]
 
@@ -622,6 +622,11 @@ def NCC_algorithem(leftImage, rigthImage, winSize, dispRange, want_cost=False):
     check(lib().smt_ncc(_ptr(leftImage), _ptr(rigthImage), H, W, dispRange, winSize, _ptr(disp), _ptr(cost),
                         current_stream_ptr()), "smt_ncc")
     return (disp, cost) if want_cost else disp
+
+
+def ncc_set_impl(impl):
+    """2 = window statistics + dot4 cross term (default), 1 = the reference's loop nest (test hook)."""
+    check(lib().smt_ncc_set_impl(int(impl)), "smt_ncc_set_impl")
 
 
 def asw_masks(winSize, spaceSigma, colorSigma, device):

@@ -177,6 +177,187 @@ __global__ void __launch_bounds__(NT) k_ncc(const uint8_t *__restrict__ L, const
     }
 }
 
+// ---- NCC, second formulation (default) --------------------------------------------------------------------
+// k_ncc above is the reference's loop nest, one lane per hypothesis, two passes of byte loads over both windows:
+// 2.4 ms at 450x375, D=64, 21x21.  All three sums of ComputeCost are integer-valued polynomials of the bytes:
+// with n = side^2, Sa = sum a, Saa = sum a^2, Sb, Sbb likewise and Sab = sum a*b,
+//     sum (a-lm)^2 = (n*Saa - Sa^2)/n,  sum (b-rm)^2 = (n*Sbb - Sb^2)/n,  sum (a-lm)(b-rm) = (n*Sab - Sa*Sb)/n,
+// so  cost = (n*Sab - Sa*Sb) / (sqrt(n*Saa - Sa^2) * sqrt(n*Sbb - Sb^2))   (the 1/n cancel),
+// every integer exact in float64 (< 2^53).  Sa, Saa depend on the left position only and Sb, Sbb on the right
+// position only (k_ncc_stats, separable window sums, once per image); what is left per hypothesis is Sab, taken
+// four taps per v_dot4_u32_u8.  The reference accumulates the same quantities in float64 with a rounding per
+// tap; the two agree to ~1e-14 relative, the test tolerance is 1e-4 (north_star), and the cases the reference
+// turns into NaN (a flat window: 0/0) are exact zeros here too.  WinTakeAll's float-narrowed running maximum
+// (NCC.h:53-67) is evaluated in parallel: m before step d equals the maximum of (float)c[e] over e < d (NaN
+// entries skipped, a NaN at d = 0 poisons everything), so d wins iff c[d] > that prefix maximum, and the answer
+// is the last winner.
+constexpr int NCP = 16;                                   // pixels (waves) per workgroup
+constexpr int NCT = 16;                                   // rows per k_ncc_stats tile
+
+__global__ void __launch_bounds__(256) k_ncc_stats(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int H, int W,
+                                                   int win, int *__restrict__ sumL, double *__restrict__ rootL,
+                                                   int *__restrict__ sumR, double *__restrict__ rootR)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int side = 2 * win + 1, RC = 64 + 2 * win, RR = NCT + 2 * win;
+    uint8_t *raw = smem;                                  // [RR][RC]
+    int *hs = (int *)(smem + (((size_t)RR * RC + 15) & ~(size_t)15));   // [RR][64] row-window sums
+    int *hq = hs + RR * 64;                               // [RR][64] row-window sums of squares
+    const uint8_t *img = blockIdx.z == 0 ? L : R;
+    int *osum = blockIdx.z == 0 ? sumL : sumR;
+    double *oroot = blockIdx.z == 0 ? rootL : rootR;
+    const int y0 = win + blockIdx.y * NCT, x0 = win + blockIdx.x * 64;   // first output of the tile
+    for (int e = threadIdx.x; e < RR * RC; e += 256) {
+        const int r = e / RC, c = e - r * RC;
+        const int yy = min(y0 - win + r, H - 1), xx = min(x0 - win + c, W - 1);   // >= 0 by construction
+        raw[e] = img[(size_t)yy * W + xx];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RR * 64; e += 256) {
+        const int r = e >> 6, x = e & 63;
+        int s1 = 0, s2 = 0;
+        for (int c = 0; c < side; c++) { const int v = raw[r * RC + x + c]; s1 += v; s2 += v * v; }
+        hs[e] = s1; hq[e] = s2;
+    }
+    __syncthreads();
+    const double n = (double)(side * side);
+    for (int e = threadIdx.x; e < NCT * 64; e += 256) {
+        const int y = e >> 6, x = e & 63;
+        if (y0 + y >= H - win || x0 + x >= W - win) continue;
+        int s1 = 0, s2 = 0;
+        for (int r = 0; r < side; r++) { s1 += hs[(y + r) * 64 + x]; s2 += hq[(y + r) * 64 + x]; }
+        const size_t p = (size_t)(y0 + y) * W + x0 + x;
+        osum[p] = s1;
+        oroot[p] = sqrt(n * (double)s2 - (double)s1 * (double)s1);   // both products < 2^53: exact, and so is the difference
+    }
+}
+
+// One ds_read_b32 that stays one (see lds_f64 below in the ASW section: merged wide reads of 4-byte-aligned
+// addresses are serialised by the LDS -- 65 LDS cycles per instruction measured here).
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t *p)
+{
+    return *(const volatile __attribute__((address_space(3))) uint32_t *)p;
+}
+
+// inclusive prefix maximum over the lanes of a wave (f32; NaN-free input)
+__device__ __forceinline__ float wave_prefix_max_f32(float v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(v, off, WAVE);
+        if (lane >= off) v = fmaxf(v, o);
+    }
+    return v;
+}
+
+template <int K, int G>
+__global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int H, int W,
+                                                   int D, int win, const int *__restrict__ sumL,
+                                                   const double *__restrict__ rootL, const int *__restrict__ sumR,
+                                                   const double *__restrict__ rootR, int RW, int CS,
+                                                   int32_t *__restrict__ disp, double *__restrict__ cost_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int side = 2 * win + 1;
+    // LDS: the right image's rows under the workgroup as 4 byte-shifted dword copies (copy s, dword w = bytes
+    // xlo + 4w + s .. + 3: any unaligned dword of a row is an aligned dword of one copy), the raw rows they are
+    // built from, and each pixel's left window as dwords of 4 taps (zero past the window's last column)
+    uint32_t *s_R = (uint32_t *)smem;                     // [4][CS], row r of copy s at s * CS + r * RW
+    uint32_t *s_raw = s_R + 4 * CS;                       // [side][RW + 1]
+    uint32_t *s_A = s_raw + side * (RW + 1);              // [NCP][side * G]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = win + blockIdx.y, j0 = win + blockIdx.x * NCP;
+    const int xlo = ((j0 - win - (64 * K - 1)) >> 2) << 2;               // first staged column (multiple of 4, may be < 0)
+    for (int e = threadIdx.x; e < side * (RW + 1); e += NCP * 64) {
+        const int r = e / (RW + 1), w = e - r * (RW + 1);
+        const uint8_t *row = R + (size_t)(i - win + r) * W;
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int x = xlo + 4 * w + b;
+            x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);      // columns outside the image only feed sentinel hypotheses
+            v |= (uint32_t)row[x] << (8 * b);
+        }
+        s_raw[e] = v;
+    }
+    const int j = j0 + wv;
+    const bool live = j < W - win;
+    {
+        const int jc = live ? j : W - win - 1;
+        for (int t = lane; t < side * G; t += 64) {
+            const int r = t / G, g = t - r * G;
+            const uint8_t *row = L + (size_t)(i - win + r) * W + (jc - win) + 4 * g;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * g + b < side) v |= (uint32_t)row[b] << (8 * b);
+            s_A[wv * side * G + t] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * side * RW; e += NCP * 64) {
+        const int sft = e / (side * RW), rem = e - sft * (side * RW), r = rem / RW, w = rem - r * RW;
+        s_R[sft * CS + r * RW + w] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
+    }
+    __syncthreads();
+    if (!live) return;
+    const int p = i * W + j;
+    unsigned sab[K];
+    const uint32_t *bk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int d = lane + 64 * k;
+        const int o = (j - win - d) - xlo;                // >= 0: xlo <= j0 - win - (64K - 1)
+        bk[k] = s_R + (o & 3) * CS + (o >> 2);
+        sab[k] = 0u;
+    }
+    const uint32_t *ap = s_A + wv * side * G;
+    for (int r = 0; r < side; r++) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t a = lds_u32(ap + g);           // one address for the whole wave: a broadcast read
+#pragma unroll
+            for (int k = 0; k < K; k++) sab[k] = __builtin_amdgcn_udot4(a, lds_u32(bk[k] + g), sab[k], false);
+        }
+        ap += G;
+#pragma unroll
+        for (int k = 0; k < K; k++) bk[k] += RW;
+    }
+    // cost per hypothesis (float64), then WinTakeAll
+    const double n = (double)(side * side);
+    const double sa = (double)sumL[p], ra = rootL[p];
+    double c[K];
+    float carry = 0.0f;                                   // prefix maximum of the slots already done
+    bool poison = false;
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int d = lane + 64 * k;
+        const bool act = d < D;
+        if (act && j - win - d >= 0) {
+            const size_t q = (size_t)p - d;
+            const double num = n * (double)sab[k] - sa * (double)sumR[q];
+            c[k] = num / (ra * rootR[q]);
+        } else c[k] = 255.0;                              // `invalid` 0xff, NCC.h:88
+        if (cost_out && act) cost_out[(size_t)p * D + d] = c[k];
+        // m before step d = max over e < d of (float)c[e] with NaNs skipped; a NaN at d = 0 makes every test false
+        const bool isn = c[k] != c[k];
+        if (k == 0) poison = __builtin_amdgcn_readfirstlane((int)isn) != 0;
+        const float gk = (act && !isn) ? (float)c[k] : -INFINITY;
+        float inc = wave_prefix_max_f32(gk, lane);
+        float exc = __shfl_up(inc, 1, WAVE);
+        if (lane == 0) exc = -INFINITY;
+        if (k > 0) exc = fmaxf(exc, carry);
+        const bool win_d = act && (k > 0 || lane > 0) && ((double)exc < c[k]);
+        const unsigned long long wm = __ballot(win_d);
+        if (wm) best = 64 * k + 63 - __builtin_clzll(wm);
+        carry = fmaxf(carry, __shfl(inc, 63, WAVE));
+        if (k == 0) carry = __shfl(inc, 63, WAVE);
+    }
+    if (lane == 0) disp[p] = poison ? 0 : best;
+}
+
 // ---------------------------------------------------------------------------------- ASW
 // Per hypothesis: cost = sum_q w0(q) w1(q) e(q) / sum_q w0(q) w1(q) over the (2*wins+1)^2 window, with
 // w0 = color[|A(q)-A(c)|]*space(q) (anchor window, independent of d), w1 = color[|B(q)-B(c)|]*space(q)
@@ -535,12 +716,70 @@ SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     return SMT_OK;
 }
 
+static int g_ncc_impl = 2;   // 2: k_ncc_stats + k_ncc2 (default); 1: k_ncc (the reference's loop nest, also the fallback for windows wider than 31)
+SMT_API int smt_ncc_set_impl(int impl)
+{
+    if (impl != 1 && impl != 2) return SMT_ERR_ARG;
+    g_ncc_impl = impl;
+    return SMT_OK;
+}
+
+template <int K>
+static int launch_ncc2(int G, dim3 grid, size_t shm, hipStream_t st, const uint8_t *L, const uint8_t *R, int H, int W, int D,
+                       int win, const int *sumL, const double *rootL, const int *sumR, const double *rootR, int RW, int CS,
+                       int32_t *disp, double *cost)
+{
+#define SMT_NCC2(GG)                                                                                          \
+    case GG:                                                                                                  \
+        SMT_HIP(hipFuncSetAttribute((const void *)k_ncc2<K, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        hipLaunchKernelGGL((k_ncc2<K, GG>), grid, dim3(NCP * 64), shm, st, L, R, H, W, D, win, sumL, rootL, sumR, rootR, RW, CS, disp, cost); \
+        break
+    switch (G) {
+        SMT_NCC2(1); SMT_NCC2(2); SMT_NCC2(3); SMT_NCC2(4); SMT_NCC2(5); SMT_NCC2(6); SMT_NCC2(7); SMT_NCC2(8);
+    default: return SMT_ERR_ARG;
+    }
+#undef SMT_NCC2
+    return SMT_OK;
+}
+
 SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int winSize, int32_t *disp,
                     double *cost, void *stream)
 {
     if (!L || !R || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256 || winSize < 0) return SMT_ERR_ARG;
     const int N = H * W;
-    hipLaunchKernelGGL(k_ncc, dim3((N + 3) / 4), dim3(NT), 0, smt_stream(stream), L, R, H, W, D, winSize, disp, cost);
+    hipStream_t st = smt_stream(stream);
+    const int side = 2 * winSize + 1, Hi = H - 2 * winSize, Wi = W - 2 * winSize;
+    if (g_ncc_impl == 2 && side <= 31) {
+        SMT_HIP(hipMemsetAsync(disp, 0, (size_t)N * 4, st));             // border pixels: 0, like k_ncc
+        if (Hi <= 0 || Wi <= 0) return SMT_OK;
+        int *sums = nullptr;
+        double *roots = nullptr;
+        if (hipMallocAsync((void **)&roots, (size_t)N * 8 * 2, st) == hipSuccess) {
+            if (hipMallocAsync((void **)&sums, (size_t)N * 4 * 2, st) != hipSuccess) { (void)hipFreeAsync(roots, st); return SMT_ERR_ALLOC; }
+            const int RR = NCT + 2 * winSize, RC = 64 + 2 * winSize;
+            const size_t shm1 = (((size_t)RR * RC + 15) & ~(size_t)15) + (size_t)RR * 64 * 8;
+            hipLaunchKernelGGL(k_ncc_stats, dim3((Wi + 63) / 64, (Hi + NCT - 1) / NCT, 2), dim3(256), shm1, st, L, R, H, W, winSize,
+                               sums, roots, sums + N, roots + N);
+            const int K = (D + 63) / 64, G = (side + 3) / 4;
+            const int RW = 16 * K + G + 4, CS = (side * RW + 31) / 32 * 32 + 8;
+            const size_t shm2 = ((size_t)4 * CS + (size_t)side * (RW + 1) + (size_t)NCP * side * G) * 4;
+            const dim3 grid((Wi + NCP - 1) / NCP, Hi);
+            int rc;
+            switch (K) {
+            case 1: rc = launch_ncc2<1>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
+            case 2: rc = launch_ncc2<2>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
+            case 3: rc = launch_ncc2<3>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
+            default: rc = launch_ncc2<4>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
+            }
+            (void)hipFreeAsync(sums, st);
+            (void)hipFreeAsync(roots, st);
+            if (rc != SMT_OK) return rc;
+            SMT_LAUNCH_CHECK();
+            return SMT_OK;
+        }
+        // no scratch memory: the first formulation below
+    }
+    hipLaunchKernelGGL(k_ncc, dim3((N + 3) / 4), dim3(NT), 0, st, L, R, H, W, D, winSize, disp, cost);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }
