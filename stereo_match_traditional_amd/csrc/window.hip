@@ -12,6 +12,7 @@
 // 422-425) make cost[d] = cost[dmax] for d beyond the last in-range disparity dmax, i.e.
 // the hypothesis is evaluated at min(d, dmax).
 #include "smt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -749,13 +750,14 @@ SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int
     const int N = H * W;
     hipStream_t st = smt_stream(stream);
     const int side = 2 * winSize + 1, Hi = H - 2 * winSize, Wi = W - 2 * winSize;
-    if (g_ncc_impl == 2 && side <= 31) {
+    static const int env_impl = [] { const char *e = getenv("SMT_NCC_IMPL"); return e ? atoi(e) : 0; }();   // debugging aid: overrides smt_ncc_set_impl
+    if ((env_impl ? env_impl : g_ncc_impl) == 2 && side <= 31) {
         SMT_HIP(hipMemsetAsync(disp, 0, (size_t)N * 4, st));             // border pixels: 0, like k_ncc
         if (Hi <= 0 || Wi <= 0) return SMT_OK;
         int *sums = nullptr;
         double *roots = nullptr;
-        if (hipMallocAsync((void **)&roots, (size_t)N * 8 * 2, st) == hipSuccess) {
-            if (hipMallocAsync((void **)&sums, (size_t)N * 4 * 2, st) != hipSuccess) { (void)hipFreeAsync(roots, st); return SMT_ERR_ALLOC; }
+        if (smt_scratch_alloc((void **)&roots, (size_t)N * 8 * 2, st) == hipSuccess) {
+            if (smt_scratch_alloc((void **)&sums, (size_t)N * 4 * 2, st) != hipSuccess) { (void)hipFreeAsync(roots, st); return SMT_ERR_ALLOC; }
             const int RR = NCT + 2 * winSize, RC = 64 + 2 * winSize;
             const size_t shm1 = (((size_t)RR * RC + 15) & ~(size_t)15) + (size_t)RR * 64 * 8;
             hipLaunchKernelGGL(k_ncc_stats, dim3((Wi + 63) / 64, (Hi + NCT - 1) / NCT, 2), dim3(256), shm1, st, L, R, H, W, winSize,
@@ -817,20 +819,8 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         hipStream_t st = smt_stream(stream);
         double *w0 = nullptr;
         unsigned *a32 = nullptr;
-        {
-            // keep the stream-ordered pool's memory between calls (the default releases it at every sync)
-            static bool pool_set[64] = {};
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !pool_set[dev]) {
-                hipMemPool_t pool = nullptr;
-                unsigned long long keep = ~0ull;
-                if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
-                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                pool_set[dev] = true;
-            }
-        }
-        if (shm3 <= 160 * 1024 && hipMallocAsync((void **)&w0, nt * 8, st) == hipSuccess) {
-            if (hipMallocAsync((void **)&a32, na * 4, st) != hipSuccess) { (void)hipFreeAsync(w0, st); return SMT_ERR_ALLOC; }
+        if (shm3 <= 160 * 1024 && smt_scratch_alloc((void **)&w0, nt * 8, st) == hipSuccess) {
+            if (smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { (void)hipFreeAsync(w0, st); return SMT_ERR_ALLOC; }
             const uint8_t *Ap = v == 0 ? Lp : Rp;
             hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32);
             const dim3 grid((W + A3P * A3Q - 1) / (A3P * A3Q), H);
