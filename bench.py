@@ -96,6 +96,10 @@ def pmc_traffic(workload):
 
 def smi_snapshot():
     """Best-effort rocm-smi readings (child process; never fatal): temperatures, clocks, power."""
+    # under rocprofv3 the child would inherit the profiler's GPU-initialising preload and then exec rocm-smi's
+    # interpreter, which the GPU boxes refuse: no snapshot there
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     try:
         r = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower", "--json"], capture_output=True,
                            text=True, timeout=20)

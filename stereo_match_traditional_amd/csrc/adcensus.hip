@@ -349,22 +349,28 @@ constexpr int FPW = FTJ / 4;      // consecutive pixels per wave
 // larger than L2 + Infinity Cache, so they should not displace the tables the next workgroups read.
 // With the XCD-contiguous chunk order this is worth 5-6 % of the kernel (A/B); with chunks in
 // dispatch order it cost 4 %.
+// The volume stores are buffer stores: SGPR resource (base = the wave's first pixel, range = the wave's run, so a
+// store past the run is dropped by the hardware) + a constant VGPR lane offset + an SGPR offset that advances by
+// one pixel (D * 4 bytes) with a scalar add -- no vector instruction is spent on store addresses.  aux = 2 is the
+// nt bit of gfx940+ (what __builtin_nontemporal_store puts on a global_store).
+typedef int si2 __attribute__((ext_vector_type(2)));
+typedef int si3 __attribute__((ext_vector_type(3)));
+typedef int si4 __attribute__((ext_vector_type(4)));
 template <int C, bool NTS = true>
-__device__ __forceinline__ void st_stream(float *p, const float (&v)[C])
+__device__ __forceinline__ void st_stream(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float (&v)[C])
 {
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));   // rows of 192 floats: 12-byte lane stride
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    if (C == 1) { if (NTS) __builtin_nontemporal_store(v[0], p); else *p = v[0]; }
+    constexpr int AUX = NTS ? 2 : 0;
+    if (C == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[0]), r, voff, soff, AUX);
     else if (C == 2) {
-        f2v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0];
-        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f2v *>(p)); else *reinterpret_cast<f2v *>(p) = x;
+        si2 x; x.x = __float_as_int(v[0]); x.y = __float_as_int(v[C > 1 ? 1 : 0]);
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, AUX);
     } else if (C == 3) {
-        f3v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0]; x.z = v[C > 2 ? 2 : 0];
-        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f3v *>(p)); else *reinterpret_cast<f3v *>(p) = x;
+        si3 x; x.x = __float_as_int(v[0]); x.y = __float_as_int(v[C > 1 ? 1 : 0]); x.z = __float_as_int(v[C > 2 ? 2 : 0]);
+        __builtin_amdgcn_raw_buffer_store_b96(x, r, voff, soff, AUX);
     } else {
-        f4v x; x.x = v[0]; x.y = v[C > 1 ? 1 : 0]; x.z = v[C > 2 ? 2 : 0]; x.w = v[C > 3 ? 3 : 0];
-        if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p)); else *reinterpret_cast<f4v *>(p) = x;
+        si4 x; x.x = __float_as_int(v[0]); x.y = __float_as_int(v[C > 1 ? 1 : 0]); x.z = __float_as_int(v[C > 2 ? 2 : 0]);
+        x.w = __float_as_int(v[C > 3 ? 3 : 0]);
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, AUX);
     }
 }
 
@@ -452,23 +458,39 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
     }
     const char *lutA = (const char *)s_lut;
     const float *lutC = s_lut + 256;
-    float *out = vol + ((size_t)i * W + j0 + p0) * D + dlr;
+    const unsigned ooff = (unsigned)dlr * 4u;
+    unsigned osoff = 0;                                      // scalar byte offset of the current pixel in the wave's run
     int res = 0;
     const int npx = min(FPW, W - (j0 + p0));                 // uniform; may be <= 0
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(vol + ((size_t)i * W + j0 + p0) * D), 0, (npx > 0 ? npx : 0) * D * 4, 0x00020000);
     // interior run: every pixel of this wave has all 63 taps inside the image, so the tap mask is
     // all ones and the two ANDs per hypothesis can be dropped (bit 63 is 0 in every table entry)
     const bool interior = (i >= 4) && (i < H - 4) && (j0 + p0 >= 3) && (j0 + p0 + npx - 1 <= W - 4);
 
     auto run = [&](auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        // The anchor entries are read at wave-uniform LDS addresses.  The two addresses live in VGPRs that advance
+        // once per group of C pixels (the pixels of a group use immediate offsets); left to itself the compiler keeps
+        // them in SGPRs and spends two v_mov per pixel to feed the ds_read.
+        typedef const __attribute__((address_space(3))) uint64_t *lds_u64_p;
+        typedef const __attribute__((address_space(3))) uint16_t *lds_u16_p;
+        uint32_t anc_a = (uint32_t)(size_t)(const __attribute__((address_space(3))) Anchor *)(s_anc + p0);
+        uint32_t val_a = (uint32_t)(size_t)(const __attribute__((address_space(3))) uint16_t *)(s_vala + p0);
+        asm volatile("" : "+v"(anc_a), "+v"(val_a));
         for (int g = 0; g < npx; g += C) {
 #pragma unroll
             for (int u = 0; u < C; u++) {
                 const int q = g + u;
                 if (q < npx) {
-                    const int p = p0 + q;
-                    const Anchor a = s_anc[p];
-                    const unsigned va = s_vala[p];
+                    Anchor a;
+                    if (MASKED) {                                            // one ds_read_b128
+                        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                        const u64x2 v = *(const __attribute__((address_space(3))) u64x2 *)(size_t)(anc_a + 16u * u);
+                        a.cen = v.x; a.mask = v.y;
+                    }
+                    else { a.cen = *(lds_u64_p)(size_t)(anc_a + 16u * u); a.mask = 0; }
+                    const unsigned va = *(lds_u16_p)(size_t)(val_a + 2u * u);
                     // entry that joins the ring for the next pixel (always inside the staged range)
                     const int nn = (VIEW == 0) ? (q + 1) : (q + C);
                     const uint64_t nc = s_cenx[e0 + nn];
@@ -487,17 +509,13 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
                         c[k] = *(const float *)(lutA + ad4) + lutC[hd];
                         key[k] = ok[k] ? __float_as_uint(c[k]) : 0xFFFFFFFFu;
                     }
-                    if (FULL) {
-                        vecf<C> pk;
-#pragma unroll
-                        for (int k = 0; k < C; k++) pk.v[k] = c[k];
-                        st_stream<C, NTS>(out, pk.v);
-                    } else {
+                    if (FULL) st_stream<C, NTS>(orsrc, ooff, osoff, c);
+                    else {
 #pragma unroll
                         for (int k = 0; k < C; k++)
-                            if (ok[k]) { if (NTS) __builtin_nontemporal_store(c[k], out + k); else out[k] = c[k]; }
+                            if (ok[k]) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(c[k]), orsrc, ooff + 4u * k, osoff, NTS ? 2 : 0);
                     }
-                    out += D;
+                    osoff += (unsigned)D * 4u;
                     if (disp) {
                         unsigned ml = key[0];
 #pragma unroll
@@ -517,6 +535,7 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
                     rc[ns] = nc; rv[ns] = nv;
                 }
             }
+            anc_a += 16u * C; val_a += 2u * C;
         }
     };
     if (interior) run(std::false_type{});
@@ -589,13 +608,16 @@ __global__ void __launch_bounds__(NT) k_store_only2(int H, int W, float *__restr
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = bx * FTJ, p0 = wid * FPW;
     const int npx = min(FPW, W - (j0 + p0));
-    float *out = vol + ((size_t)i * W + j0 + p0) * D + lane * C;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(vol + ((size_t)i * W + j0 + p0) * D), 0, (npx > 0 ? npx : 0) * D * 4, 0x00020000);
+    const unsigned ooff = (unsigned)(lane * C) * 4u;
+    unsigned osoff = 0;
     float x[C];
 #pragma unroll
     for (int k = 0; k < C; k++) x[k] = (float)(lane + k);
     for (int q = 0; q < npx; q++) {
-        st_stream<C>(out, x);
-        out += D;
+        st_stream<C>(orsrc, ooff, osoff, x);
+        osoff += (unsigned)D * 4u;
         x[0] += 1.0f;
     }
 }
