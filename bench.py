@@ -6,6 +6,9 @@ One process per GPU (torch.distributed over RCCL when N > 1); pairs are independ
 its own pairs with no data-path collective (weak scaling); config 5's only exchange -- one all_gather of
 the disparity maps + a checksum all_reduce (shard.py) -- sits at the end of the timed region unless
 --no-gather is given, and is also timed by itself (extra.gather_ms).
+A step is one smt_adcensus_compute_batch call over --pairs-per-step (default 8) resident pairs: the steady-state
+throughput configuration (from the second pair of a batch on, the table kernels of the next pair overlap the
+cost kernel of the current one); the latency of a lone pair is reported beside it (ms_single_pair_call).
 Prints ONE JSON line on rank 0.  After the timed region rank 0 also measures, outside `value`:
   roofline.sclk_mhz / store_ceiling_ms   in-kernel shader clock of the cost kernel and the same-run
                                          store-only ceiling of its store pattern (smt_adcensus_diag);
@@ -262,7 +265,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="adcensus_1080p_d192", choices=sorted(WORKLOADS))
-    ap.add_argument("--pairs-per-step", type=int, default=1, help="pairs per step PER GPU (config 5: 256/N)")
+    ap.add_argument("--pairs-per-step", type=int, default=8,
+                    help="pairs per step PER GPU, one smt_adcensus_compute_batch call (config 5: 256/N); from the second pair "
+                         "of a batch on, the table kernels of pair n+1 overlap the cost kernel of pair n")
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the disparity gather out of the timed region")
     ap.add_argument("--no-extras", action="store_true", help="skip extra.configs (configs 1-5 after the timed region)")
@@ -339,6 +344,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, gather_ms = float(tt[0].item()), (float(tt[1].item()) if gather_ms is not None else None)
 
+    # latency of a lone pair (one call, nothing to overlap with), outside the timed region
+    single_ms = None
+    if rank == 0:
+        single_ms = ev_timed(lambda: adc.ComputeBatch(Lb[:1], Rb[:1], dl[:1], dr[:1]), 20, warm=2)
     # same-run diagnostics of the dominant kernel, right after the timed region (same DVFS / memory state)
     diag = None
     if rank == 0 and D % 64 == 0:
@@ -387,6 +396,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "ms_per_pair": round(dt / (args.steps * P) * 1e3, 4),
+            "ms_single_pair_call": round(single_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
