@@ -316,9 +316,9 @@ def main():
         shard.gather_disparities(dl, world * P)
         shard.checksum(dl)
     barrier()
-    # HIP events around the kernels of every 4th pair (each record costs ~3 us of stream time; all of
-    # them when the run is short)
-    stride = 4 if args.steps * P >= 40 else 1
+    # HIP events around the kernels of ~32 pairs spread over the run (each record costs ~3 us of stream time and
+    # a timed pair carries four)
+    stride = max(1, (args.steps * P) // 32)               # ~32 timed pairs per run
     adc.timing(stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
