@@ -9,7 +9,7 @@ property-checked.
 The oracle is PARITY UNPINNED for these stages (no reference build without OpenCV, no reference
 fixtures); these hashes pin the HIP path to the oracle, not the oracle to the reference.
 
-Run:  SMT_ORACLE_OMP=1 python tests/golden/make_config_hashes.py [cfg2] [cfg3] [cfg5] [--pairs N]
+Run:  SMT_ORACLE_OMP=1 python tests/golden/make_config_hashes.py [cfg2] [cfg3] [cfg5] [a18] [--pairs N]
 (OpenMP build of the same oracle file: planes / rows / lines are independent, results identical.)
 cfg3 needs ~12 GB of host memory and ~10 min on 8 cores; cfg5 (256 pairs) ~35 min.
 """
@@ -143,6 +143,32 @@ def cfg5(db, pairs):
     save(db)
 
 
+def a18(db):
+    """CrossAggregator at its benchmark size, by the REFERENCE's own code (oracle/_ref, built from
+    /root/reference/CBLSM/cross_aggregator.cpp by oracle/Makefile) -- the one pinned stage.  cost_init = config 2's
+    left AD-Census volume, BGR = gray + (LCG byte mod 3) per channel, ADCensusOption's parameters."""
+    from stereo_match_traditional_amd import synth
+    H, W, D, seed = 720, 1280, 128, 2
+    L, R = O.synth_pair(H, W, D, seed)
+    bgr = np.clip(L.astype(np.int32)[..., None] + (synth.lcg_bytes(seed + 500, H * W * 3)[0] % 3).reshape(H, W, 3), 0, 255).astype(np.uint8)
+    cost = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
+    rec = {"H": H, "W": W, "D": D, "seed": seed, "bgr_seed": seed + 500, "L1": 34, "L2": 17, "t1": 20, "t2": 6, "iters": 4,
+           "cost_init": "adcensus_vol_left of cfg2", "cost_init_hash": hx(cost)}
+    assert O.have_ref(), "oracle/_ref missing: make -C oracle ref (needs /root/reference)"
+    t = time.time()
+    arms, out = O.ref_crossagg(bgr, cost, 34, 17, 20, 6, 4)
+    log("a18 reference build done in %.0f s" % (time.time() - t))
+    arms2, out2 = O.crossagg(bgr, cost, 34, 17, 20, 6, 4)
+    assert np.array_equal(arms, arms2) and np.array_equal(out.view(np.uint32), out2.view(np.uint32)), "oracle != reference build"
+    rec["arms"] = hx(arms)
+    rec["cost"] = hx(out)
+    rec["disp"] = hx(O.wta(out))
+    rec["produced_by"] = "reference build (oracle/_ref/libcrossagg_ref.so); the oracle restatement gives the same bits"
+    db["a18_crossaggregator_720p_d128"] = rec
+    save(db)
+    log("a18 done")
+
+
 if __name__ == "__main__":
     O.build()
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -158,3 +184,5 @@ if __name__ == "__main__":
         cfg3(db)
     if "cfg5" in which:
         cfg5(db, pairs)
+    if "a18" in which:
+        a18(db)

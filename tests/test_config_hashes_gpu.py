@@ -182,3 +182,33 @@ def test_pipeline_batch_small_pairs_vs_oracle(smt, O):
         assert np.array_equal(dr[b].cpu().numpy(), d_r) and np.array_equal(cls[b].cpu().numpy(), c)
         assert tuple(counts[b].cpu().tolist()) == (no, nm)
     pipe.close()
+
+
+def test_a18_crossaggregator_full_size_vs_reference_build(smt, O, gold):
+    """CrossAggregator at 1280x720 D=128, ADCensusOption's parameters, 4 iterations, fed with config 2's left AD-Census
+    volume computed on the device: arms, aggregated volume and WTA map against hashes produced by the REFERENCE's own
+    cross_aggregator.cpp (oracle/_ref, tests/golden/make_config_hashes.py a18) -- the pinned stage at its benchmark size.
+    Both HIP formulations (shared-tap passes, one pixel per wave)."""
+    from stereo_match_traditional_amd import synth
+    rec = gold["a18_crossaggregator_720p_d128"]
+    H, W, D = rec["H"], rec["W"], rec["D"]
+    L, R = synth.synth_pair(H, W, D, rec["seed"])
+    bgr = np.clip(L.astype(np.int32)[..., None] + (synth.lcg_bytes(rec["bgr_seed"], H * W * 3)[0] % 3).reshape(H, W, 3), 0, 255).astype(np.uint8)
+    adc = smt.AD_Census().Initialize(T(L.astype(np.float32)), T(R.astype(np.float32)), D, H, W, 10.0, 30.0)
+    adc.ComputeBoth()
+    cost = adc.GetPtrLeft().clone()
+    adc.close()
+    assert hx(O, cost) == rec["cost_init_hash"]
+    b = T(bgr)
+    for impl in (2, 1):
+        ca = smt.CrossAggregator()
+        ca.Initialize(W, H, 0, D, DEV)
+        ca.set_impl(impl)
+        ca.SetData(b, b, cost)
+        ca.SetParams(rec["L1"], rec["L2"], rec["t1"], rec["t2"])
+        ca.Aggregate(rec["iters"])
+        check(O, rec, "arms", ca.get_arms_ptr())
+        out = ca.get_cost_ptr()
+        check(O, rec, "cost", out)
+        check(O, rec, "disp", smt.wta(out))
+        ca.close()
