@@ -3,9 +3,17 @@
 //   uchar gray pair -> float copies (:46-55) -> AD_Census both views + WTA (:57-61) -> CrossArmAggregation on
 //   the left and on the right image (:67-84) -> ScanlineOptimizer on the LEFT aggregated volume guided by the
 //   float left image (:86-89, enabled) -> LeftRightConsistency (:92).
-// Nothing here computes: it sequences the library's own entry points on one stream and owns the three
-// [H][W][D] volumes between the stages, so a batch of pairs reuses them (9.6 GB at 1920x1080x192 whatever
-// the batch size).  Pairs are independent, which makes this the sharding unit for the pair axis.
+// Nothing here computes: it sequences the library's own entry points and owns the three [H][W][D] volumes
+// between the stages, so a batch of pairs reuses them (9.6 GB at 1920x1080x192 whatever the batch size).
+// Pairs are independent, which makes this the sharding unit for the pair axis.
+// Schedule: everything of a pair runs on the caller's stream except the right view's arms + aggregation, which
+// run on an internal stream beside the scanline optimiser of the left view (tools/overlap_probe.py: the
+// scanline passes are HBM / latency bound with 2 160 waves in flight, the aggregation is vector-issue bound;
+// side by side they take 8.75 ms where one after the other takes 9.65 at 1920x1080 D=192; a high-priority stream
+// or raised wave priority for the scanline, or compute units masked out of the aggregation's stream, all measured
+// worse or equal).  Event edges per pair:
+//   aggregate(left) --ev_left--> side: arms(right), aggregate(right) --ev_right--> main: LR check
+// and the next pair's AD-Census (which overwrites the cost volumes) comes after that wait on the main stream.
 #include "smt_common.h"
 #include <new>
 
@@ -14,6 +22,8 @@ struct smt_pipeline {
     int H, W, D;
     smt_pipeline_params P;
     hipStream_t stream;
+    hipStream_t side;        // right-view arms + aggregation
+    hipEvent_t ev_left, ev_right;
     smt_adcensus *adc;
     smt_crossarm *ca;
     smt_scanline *so;
@@ -35,6 +45,9 @@ SMT_API int smt_pipeline_destroy(smt_pipeline *h)
     if (h->adc) smt_adcensus_destroy(h->adc);
     if (h->ca) smt_crossarm_destroy(h->ca);
     if (h->so) smt_scanline_destroy(h->so);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_left) (void)hipEventDestroy(h->ev_left);
+    if (h->ev_right) (void)hipEventDestroy(h->ev_right);
     (void)hipFree(h->Lf); (void)hipFree(h->Rf);
     (void)hipFree(h->agg[0]); (void)hipFree(h->agg[1]); (void)hipFree(h->sovol);
     delete h;
@@ -61,6 +74,9 @@ SMT_API int smt_pipeline_create(int H, int W, int D, const smt_pipeline_params *
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->agg[0], V * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->agg[1], V * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->sovol, V * 4);
+    if (rc == SMT_OK && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) rc = SMT_ERR_HIP;
+    if (rc == SMT_OK && hipEventCreateWithFlags(&h->ev_left, hipEventDisableTiming) != hipSuccess) rc = SMT_ERR_HIP;
+    if (rc == SMT_OK && hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming) != hipSuccess) rc = SMT_ERR_HIP;
     if (rc != SMT_OK) { smt_pipeline_destroy(h); return rc; }
     *out = h;
     return SMT_OK;
@@ -103,11 +119,21 @@ SMT_API int smt_pipeline_run_batch(smt_pipeline *h, const uint8_t *grayL, const 
         if (rc == SMT_OK) rc = smt_adcensus_volume(h->adc, SMT_VIEW_RIGHT, &vol[1]);
         if (rc == SMT_OK) rc = smt_crossarm_arms(h->ca, L8, 1);                        // :67-72
         if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->ca, vol[0], h->agg[0], 0, nullptr);   // :73 (its WTA :75 is overwritten by :89)
+        if (rc == SMT_OK && hipEventRecord(h->ev_left, h->stream) != hipSuccess) rc = SMT_ERR_HIP;
+        // right view on the side stream, beside the left view's scanline passes
+        if (rc == SMT_OK && hipStreamWaitEvent(h->side, h->ev_left, 0) != hipSuccess) rc = SMT_ERR_HIP;
+        if (rc == SMT_OK) rc = smt_crossarm_set_stream(h->ca, (void *)h->side);
         if (rc == SMT_OK) rc = smt_crossarm_arms(h->ca, R8, 1);                        // :77-81 (Initialize again: threshold reset)
         if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->ca, vol[1], h->agg[1], 0, dr);        // :82-84
+        if (rc == SMT_OK && hipEventRecord(h->ev_right, h->side) != hipSuccess) rc = SMT_ERR_HIP;
+        {
+            const int rc2 = smt_crossarm_set_stream(h->ca, st);                        // back, whatever happened
+            if (rc == SMT_OK) rc = rc2;
+        }
         if (rc == SMT_OK) rc = smt_scanline_run(h->so, h->agg[0], h->Lf, h->sovol, dl);        // :86-89
+        if (rc == SMT_OK && hipStreamWaitEvent(h->stream, h->ev_right, 0) != hipSuccess) rc = SMT_ERR_HIP;
         if (rc == SMT_OK) rc = smt_lrcheck(dl, dr, H, W, h->P.gate, cls + b * N, counts ? counts + 2 * b : nullptr, st);   // :92
-        if (rc != SMT_OK) return rc;
+        if (rc != SMT_OK) { (void)hipStreamSynchronize(h->side); return rc; }
     }
     return SMT_OK;
 }

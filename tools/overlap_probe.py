@@ -21,6 +21,7 @@ out = torch.empty((H, W, D), device=DEV)
 dL = torch.empty((H, W), device=DEV); dR = torch.empty((H, W), device=DEV)
 so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+s1h = torch.cuda.Stream(priority=-1)                    # high priority: the scanline's few waves should never wait for a slot
 
 def serial():
     caL.AggregationVertical(adc.GetPtrLeft(), aggL)
@@ -49,6 +50,37 @@ def right_first():
         so.ScanLine(aggL, Lf, out, dL)
     torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
 
+def staggered():
+    """left aggregation alone, then the scanline (HBM / latency bound, 2 160 waves) beside the right aggregation
+    (vector-issue bound)"""
+    e = torch.cuda.Event(); e.record()
+    with torch.cuda.stream(s1):
+        s1.wait_event(e)
+        caL.AggregationVertical(adc.GetPtrLeft(), aggL)
+        e1 = torch.cuda.Event(); e1.record(s1)
+        so.ScanLine(aggL, Lf, out, dL)
+    with torch.cuda.stream(s2):
+        s2.wait_event(e1)
+        caR.AggregationVertical(adc.GetPtrRight(), aggR, dR)
+    torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+
+
+def staggered_prio():
+    """as staggered, the scanline on a high-priority stream"""
+    e = torch.cuda.Event(); e.record()
+    with torch.cuda.stream(s1):
+        s1.wait_event(e)
+        caL.AggregationVertical(adc.GetPtrLeft(), aggL)
+        e1 = torch.cuda.Event(); e1.record(s1)
+    with torch.cuda.stream(s1h):
+        s1h.wait_event(e1)
+        so.ScanLine(aggL, Lf, out, dL)
+    with torch.cuda.stream(s2):
+        s2.wait_event(e1)
+        caR.AggregationVertical(adc.GetPtrRight(), aggR, dR)
+    torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s1h); torch.cuda.current_stream().wait_stream(s2)
+
+
 def timed(fn, reps=8):
     fn(); torch.cuda.synchronize()
     t = time.perf_counter()
@@ -58,7 +90,7 @@ def timed(fn, reps=8):
 
 res = {}
 for rnd in range(2):
-    for name, fn in (("serial", serial), ("two_streams", two_streams), ("right_first", right_first)):
+    for name, fn in (("serial", serial), ("two_streams", two_streams), ("right_first", right_first), ("staggered", staggered), ("staggered_prio", staggered_prio)):
         res[f"{name}_{rnd}"] = timed(fn)
 ref = (out.clone(), dL.clone(), dR.clone(), aggR.clone())
 serial(); torch.cuda.synchronize()
