@@ -220,11 +220,11 @@ def extra_configs(dev, reps=5):
     for o in (adc, caL, caR, so):
         o.close()
     del aggL, aggR, sout
-    # the same pipeline through the one batched C-ABI entry (smt_pipeline_run_batch, 3 pairs per call):
+    # the same pipeline through the one batched C-ABI entry (smt_pipeline_run_batch, 8 pairs per call):
     # launch gaps, staging and the device-side counts included, no host read-back
     pipe = smt.Pipeline(H, W, D, dev)
-    Lb3, Rb3 = torch.stack([Lu] * 3), torch.stack([Ru] * 3)
-    call_ms = ev_timed(lambda: pipe.run(Lb3, Rb3), 2) / 3
+    Lb3, Rb3 = torch.stack([Lu] * 8), torch.stack([Ru] * 8)
+    call_ms = ev_timed(lambda: pipe.run(Lb3, Rb3), 2) / 8
     pipe.status()
     pipe.close()
     out["cfg3_pipeline_1080p_d192"]["batched_entry_ms_per_pair"] = round(call_ms, 4)

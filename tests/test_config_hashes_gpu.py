@@ -158,9 +158,14 @@ def test_config3_through_the_batched_pipeline_entry(smt, O, gold):
     pipe.close()
 
 
-def test_pipeline_batch_small_pairs_vs_oracle(smt, O):
-    """Different pairs in one batch, every map against the oracle pipeline run pair by pair."""
-    H, W, D, P = 40, 96, 32, 3
+@pytest.mark.parametrize("schedule", ["default", "0", "1", "2"])
+def test_pipeline_batch_small_pairs_vs_oracle(smt, O, schedule, monkeypatch):
+    """Different pairs in one batch, every map against the oracle pipeline run pair by pair -- under each stream
+    schedule of smt_pipeline_run_batch (SMT_PIPE_SCHEDULE, read at create: 0 one stream, 1 right view beside the
+    scanline, 2 three streams with double-buffered front-end state; 5 pairs so that every event edge of 2 is used)."""
+    if schedule != "default":
+        monkeypatch.setenv("SMT_PIPE_SCHEDULE", schedule)
+    H, W, D, P = 40, 96, 32, 5
     pairs = [O.synth_pair(H, W, D, 20 + b, b == 1) for b in range(P)]
     Lb = T(np.stack([p[0] for p in pairs]))
     Rb = T(np.stack([p[1] for p in pairs]))
