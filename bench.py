@@ -231,6 +231,15 @@ def extra_configs(dev, reps=5):
     out["cfg3_pipeline_1080p_d192"]["batched_entry_frac_hbm_peak"] = round(68 * V / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del Lb3, Rb3
 
+    # ---- NCC (named in north_star): NCC_main.cpp's 21x21 window on a Middlebury-size pair ----
+    H, W, win = 375, 450, 10
+    for Dn in (64, 200):
+        L, R = synth.synth_pair(H, W, 64, 1)
+        Lt, Rt = T(L), T(R)
+        ms = ev_timed(lambda: smt.NCC_algorithem(Lt, Rt, win, Dn), 3)
+        out[f"a23_ncc21x21_450x375_d{Dn}"] = {"ms": round(ms, 4), "Mdisp_s": round((H - 2 * win) * (W - 2 * win) * Dn / ms / 1e3, 1),
+                                                "bound": "lds (one ds_read_b32 per v_dot4_u32_u8 and hypothesis slot)"}
+
     # ---- CrossAggregator (named in north_star): 4 iterations x 2 passes at 1280x720, D=128 ----
     H, W, D = 720, 1280, 128
     L, R = synth.synth_pair(H, W, D, 2)

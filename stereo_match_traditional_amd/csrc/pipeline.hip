@@ -21,8 +21,8 @@
 //   S: right(b-1) --> M                    LR check of pair b - 1, issued after aggregate(left, b): the right view of
 //                                          b - 1 has had that whole aggregation to finish, M never waits for it
 //   after the loop: S: right(last) --> M: LR check(last).  Every call leaves all its work ordered on the caller's stream.
-// SMT_PIPE_SCHEDULE=1 (the default) is the two-stream form: the right view's arms + aggregation beside the scanline
-// of the same pair, nothing double-buffered; SMT_PIPE_SCHEDULE=0 runs everything on the caller's stream.
+// SMT_PIPE_SCHEDULE=1 (the default) is the two-stream form: the left view's arms beside the AD-Census of the same pair
+// and the right view's arms + aggregation beside its scanline, nothing double-buffered; SMT_PIPE_SCHEDULE=0 runs everything on the caller's stream.
 // Measured at 1920x1080 D=192, 8 pairs per call, ms per pair: 10.7 (0), 9.66-9.76 (1), 9.61-9.66 (2) -- the third
 // stream buys 1 % for a second AD-Census handle (3.3 GB) and a second crossarm handle, hence the default.
 #include "smt_common.h"
@@ -155,16 +155,33 @@ static int pipeline_run_simple(smt_pipeline *h, const uint8_t *grayL, const uint
     const size_t N = (size_t)H * W;
     void *st = (void *)h->stream;
     const bool two = h->sched == 1;
+    if (two) {
+        int rc = SMT_OK;
+        PIPE_HIP(hipEventRecord(h->ev_in, h->stream));
+        PIPE_HIP(hipStreamWaitEvent(h->side, h->ev_in, 0));                            // the caller's inputs, for the side stream
+        if (rc != SMT_OK) return rc;
+    }
     for (int b = 0; b < pairs; b++) {
         const uint8_t *L8 = grayL + b * N, *R8 = grayR + b * N;
         float *dl = dispL + b * N, *dr = dispR + b * N;
-        int rc = smt_u8_to_f32(L8, H, W, h->Lf[0], st);                                 // main.cpp:46-55
+        int rc = SMT_OK;
+        if (two) {
+            // the left view's arms need only the image: on the side stream (behind the previous pair's right view,
+            // which used the same handle) beside this pair's AD-Census
+            rc = smt_crossarm_set_stream(h->caL, (void *)h->side);
+            if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, L8, 1);                   // :67-72
+            PIPE_HIP(hipEventRecord(h->ev_front[0], h->side));
+            const int rc2 = smt_crossarm_set_stream(h->caL, st);
+            if (rc == SMT_OK) rc = rc2;
+        }
+        if (rc == SMT_OK) rc = smt_u8_to_f32(L8, H, W, h->Lf[0], st);                   // main.cpp:46-55
         if (rc == SMT_OK) rc = smt_u8_to_f32(R8, H, W, h->Rf[0], st);
         if (rc == SMT_OK) rc = smt_adcensus_compute(h->adc[0], h->Lf[0], h->Rf[0], SMT_VIEW_BOTH, nullptr, nullptr);   // :57-61 (its WTA maps are overwritten at :75, :84)
         float *vol[2] = {nullptr, nullptr};
         if (rc == SMT_OK) rc = smt_adcensus_volume(h->adc[0], SMT_VIEW_LEFT, &vol[0]);
         if (rc == SMT_OK) rc = smt_adcensus_volume(h->adc[0], SMT_VIEW_RIGHT, &vol[1]);
-        if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, L8, 1);                       // :67-72
+        if (two) PIPE_HIP(hipStreamWaitEvent(h->stream, h->ev_front[0], 0));
+        else if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, L8, 1);                  // :67-72
         if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->caL, vol[0], h->agg[0], 0, nullptr);  // :73 (its WTA :75 is overwritten by :89)
         if (two) {
             PIPE_HIP(hipEventRecord(h->ev_left, h->stream));
