@@ -338,8 +338,13 @@ int smt_pipeline_set_stream(smt_pipeline *h, void *stream);
  *   dispL   float32 [pairs][H][W]: the scanline WTA map after the LR check (+inf = rejected)
  *   dispR   float32 [pairs][H][W]: WTA of the aggregated right volume (main.cpp:84)
  *   cls     uint8   [pairs][H][W] as smt_lrcheck;  counts int32 [pairs][2] (may be NULL)
- * Asynchronous on the handle's stream.  The volumes are reused per pair (smt_pipeline_volumes: the last
- * pair's, borrowed).  This is the sharding unit for the pair axis of config 3. */
+ * Asynchronous: the call enqueues and returns; part of the work runs on streams the handle owns (the right
+ * view's aggregation beside the left view's scanline passes, see csrc/pipeline.hip), but everything a call
+ * enqueued is ordered before whatever the caller enqueues next on the handle's stream, and after whatever the
+ * caller enqueued there before the call (the inputs).  One caller thread per handle.  The volumes are reused
+ * per pair (smt_pipeline_volumes: the last pair's, borrowed).  This is the sharding unit for the pair axis of
+ * config 3.  SMT_PIPE_SCHEDULE=0|1|2 (environment, read at create) selects the stream schedule; results
+ * are identical. */
 int smt_pipeline_run_batch(smt_pipeline *h, const uint8_t *grayL, const uint8_t *grayR, int pairs,
                            float *dispL, float *dispR, uint8_t *cls, int *counts);
 int smt_pipeline_volumes(smt_pipeline *h, float **cost_left, float **cost_right, float **agg_left,
