@@ -240,6 +240,16 @@ __device__ __forceinline__ uint32_t lds_u32(const uint32_t *p)
     return *(const volatile __attribute__((address_space(3))) uint32_t *)p;
 }
 
+// Offset (in dwords) of byte-shifted copy s of the right rows.  The 32 lanes of a half-wave read 8 groups x 4
+// copies; consecutive groups sit K dwords apart, so the copies are placed on the banks that spacing leaves free
+// (K = 3 keeps one 2-way overlap).  CS is a multiple of 32.
+template <int K>
+__device__ __forceinline__ int ncc_copy_off(int s, int CS)
+{
+    const int bank = K == 1 ? 8 * s : (K == 2 ? (s & 1) + 16 * (s >> 1) : s);
+    return s * CS + bank;
+}
+
 // inclusive prefix maximum over the lanes of a wave (f32; NaN-free input)
 __device__ __forceinline__ float wave_prefix_max_f32(float v, int lane)
 {
@@ -263,7 +273,7 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
     // LDS: the right image's rows under the workgroup as 4 byte-shifted dword copies (copy s, dword w = bytes
     // xlo + 4w + s .. + 3: any unaligned dword of a row is an aligned dword of one copy), the raw rows they are
     // built from, and each pixel's left window as dwords of 4 taps (zero past the window's last column)
-    uint32_t *s_R = (uint32_t *)smem;                     // [4][CS], row r of copy s at s * CS + r * RW
+    uint32_t *s_R = (uint32_t *)smem;                     // [4][CS], row r of copy s at ncc_copy_off<K>(s, CS) + r * RW
     uint32_t *s_raw = s_R + 4 * CS;                       // [side][RW + 1]
     uint32_t *s_A = s_raw + side * (RW + 1);              // [NCP][side * G]
     const int lane = threadIdx.x & 63;
@@ -299,42 +309,44 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
     __syncthreads();
     for (int e = threadIdx.x; e < 4 * side * RW; e += NCP * 64) {
         const int sft = e / (side * RW), rem = e - sft * (side * RW), r = rem / RW, w = rem - r * RW;
-        s_R[sft * CS + r * RW + w] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
+        s_R[ncc_copy_off<K>(sft, CS) + r * RW + w] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
     }
     __syncthreads();
     if (!live) return;
     const int p = i * W + j;
+    // Hypotheses of a lane: d = 4K * (lane / 4) + 4k + lane % 4, k = 0..K-1.  Slot k at tap group g then needs the
+    // dword 4k bytes before slot 0's, i.e. the dword slot 0 needs at group g - k: one LDS read per row position
+    // serves every slot (G + K - 1 reads per window row instead of G * K).
+    const int grp = lane >> 2, rr = lane & 3;
+    const int d0 = 4 * K * grp + rr;
     unsigned sab[K];
-    const uint32_t *bk[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int d = lane + 64 * k;
-        const int o = (j - win - d) - xlo;                // >= 0: xlo <= j0 - win - (64K - 1)
-        bk[k] = s_R + (o & 3) * CS + (o >> 2);
-        sab[k] = 0u;
-    }
+    for (int k = 0; k < K; k++) sab[k] = 0u;
+    const int o = (j - win - d0) - xlo;                   // >= 4K - 4: xlo <= j0 - win - (64K - 1), d0 <= 60K + 3
+    const uint32_t *pb = s_R + ncc_copy_off<K>(o & 3, CS) + (o >> 2) - (K - 1);
     const uint32_t *ap = s_A + wv * side * G;
     for (int r = 0; r < side; r++) {
+        uint32_t bv[G + K - 1];
+#pragma unroll
+        for (int t = 0; t < G + K - 1; t++) bv[t] = lds_u32(pb + t);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const uint32_t a = lds_u32(ap + g);           // one address for the whole wave: a broadcast read
 #pragma unroll
-            for (int k = 0; k < K; k++) sab[k] = __builtin_amdgcn_udot4(a, lds_u32(bk[k] + g), sab[k], false);
+            for (int k = 0; k < K; k++) sab[k] = __builtin_amdgcn_udot4(a, bv[g - k + K - 1], sab[k], false);
         }
         ap += G;
-#pragma unroll
-        for (int k = 0; k < K; k++) bk[k] += RW;
+        pb += RW;
     }
-    // cost per hypothesis (float64), then WinTakeAll
+    // cost per hypothesis (float64)
     const double n = (double)(side * side);
     const double sa = (double)sumL[p], ra = rootL[p];
     double c[K];
-    float carry = 0.0f;                                   // prefix maximum of the slots already done
+    float v[K];
     bool poison = false;
-    int best = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int d = lane + 64 * k;
+        const int d = d0 + 4 * k;
         const bool act = d < D;
         if (act && j - win - d >= 0) {
             const size_t q = (size_t)p - d;
@@ -342,21 +354,38 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
             c[k] = num / (ra * rootR[q]);
         } else c[k] = 255.0;                              // `invalid` 0xff, NCC.h:88
         if (cost_out && act) cost_out[(size_t)p * D + d] = c[k];
-        // m before step d = max over e < d of (float)c[e] with NaNs skipped; a NaN at d = 0 makes every test false
         const bool isn = c[k] != c[k];
-        if (k == 0) poison = __builtin_amdgcn_readfirstlane((int)isn) != 0;
-        const float gk = (act && !isn) ? (float)c[k] : -INFINITY;
-        float inc = wave_prefix_max_f32(gk, lane);
-        float exc = __shfl_up(inc, 1, WAVE);
-        if (lane == 0) exc = -INFINITY;
-        if (k > 0) exc = fmaxf(exc, carry);
-        const bool win_d = act && (k > 0 || lane > 0) && ((double)exc < c[k]);
-        const unsigned long long wm = __ballot(win_d);
-        if (wm) best = 64 * k + 63 - __builtin_clzll(wm);
-        carry = fmaxf(carry, __shfl(inc, 63, WAVE));
-        if (k == 0) carry = __shfl(inc, 63, WAVE);
+        if (k == 0) poison = __builtin_amdgcn_readfirstlane((int)isn) != 0;   // lane 0, slot 0 is d = 0
+        v[k] = (act && !isn) ? (float)c[k] : -INFINITY;
     }
-    if (lane == 0) disp[p] = poison ? 0 : best;
+    // WinTakeAll.  m before step d = max over e < d of (float)c[e] with NaNs skipped (a NaN at d = 0 makes every test
+    // false), in d order = (group of 4 lanes, slot, lane in the group):
+    //   before (grp, k, rr) = max( all of the groups < grp,  slots < k of this group,  lanes < rr of slot k )
+    float exq[K];                                         // the last two terms
+    float run = -INFINITY;                                // maximum of the slots < k of this group (same in its 4 lanes)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float inc = v[k];
+        float t1 = __shfl_up(inc, 1, 4);
+        inc = fmaxf(inc, rr >= 1 ? t1 : -INFINITY);
+        float t2 = __shfl_up(inc, 2, 4);
+        inc = fmaxf(inc, rr >= 2 ? t2 : -INFINITY);      // inclusive over the lanes of the group
+        const float below = __shfl_up(inc, 1, 4);
+        exq[k] = fmaxf(run, rr >= 1 ? below : -INFINITY);
+        run = fmaxf(run, __shfl(inc, 3, 4));
+    }
+    const float pref = wave_prefix_max_f32(run, lane);    // run = the group's maximum: inclusive over the groups
+    const float prev = __shfl(pref, (4 * grp - 1) & 63, WAVE);
+    const float before = grp >= 1 ? prev : -INFINITY;     // all of the groups < grp
+    unsigned key = 0;                                     // 1 + the largest winning d of the lane (0: none)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int d = d0 + 4 * k;
+        const float m = fmaxf(before, exq[k]);
+        if (d < D && (double)m < c[k]) key = (unsigned)d + 1u;    // d grows with k
+    }
+    const unsigned kmax = ~wave_min_u32(~key);            // the last winner
+    if (lane == 0) disp[p] = (poison || kmax == 0u) ? 0 : (int)(kmax - 1u);
 }
 
 // ---------------------------------------------------------------------------------- ASW
@@ -763,7 +792,7 @@ SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int
             hipLaunchKernelGGL(k_ncc_stats, dim3((Wi + 63) / 64, (Hi + NCT - 1) / NCT, 2), dim3(256), shm1, st, L, R, H, W, winSize,
                                sums, roots, sums + N, roots + N);
             const int K = (D + 63) / 64, G = (side + 3) / 4;
-            const int RW = 16 * K + G + 4, CS = (side * RW + 31) / 32 * 32 + 8;
+            const int RW = 16 * K + G + 4, CS = (side * RW + 31) / 32 * 32 + 32;   // + 32: room for the copies' bank offsets
             const size_t shm2 = ((size_t)4 * CS + (size_t)side * (RW + 1) + (size_t)NCP * side * G) * 4;
             const dim3 grid((Wi + NCP - 1) / NCP, Hi);
             int rc;
