@@ -238,7 +238,7 @@ def extra_configs(dev, reps=5):
         Lt, Rt = T(L), T(R)
         ms = ev_timed(lambda: smt.NCC_algorithem(Lt, Rt, win, Dn), 3)
         out[f"a23_ncc21x21_450x375_d{Dn}"] = {"ms": round(ms, 4), "Mdisp_s": round((H - 2 * win) * (W - 2 * win) * Dn / ms / 1e3, 1),
-                                                "bound": "lds (one ds_read_b32 per v_dot4_u32_u8 and hypothesis slot)"}
+                                                "bound": "lds (G + K - 1 ds_read_b32 per window row for the K slots of a lane + one broadcast read per v_dot4_u32_u8)"}
 
     # ---- CrossAggregator (named in north_star): 4 iterations x 2 passes at 1280x720, D=128 ----
     H, W, D = 720, 1280, 128
