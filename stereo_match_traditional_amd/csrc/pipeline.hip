@@ -21,8 +21,8 @@
 //   S: right(b-1) --> M                    LR check of pair b - 1, issued after aggregate(left, b): the right view of
 //                                          b - 1 has had that whole aggregation to finish, M never waits for it
 //   after the loop: S: right(last) --> M: LR check(last).  Every call leaves all its work ordered on the caller's stream.
-// SMT_PIPE_SCHEDULE=1 (the default) is the two-stream form: the left view's arms beside the AD-Census of the same pair
-// and the right view's arms + aggregation beside its scanline, nothing double-buffered; SMT_PIPE_SCHEDULE=0 runs everything on the caller's stream.
+// SMT_PIPE_SCHEDULE=1 (the default) is the two-stream form: both views' arms beside the AD-Census of the same pair and
+// the right view's aggregation (its own crossarm handle) beside the left view's scanline, nothing else double-buffered; SMT_PIPE_SCHEDULE=0 runs everything on the caller's stream.
 // Measured at 1920x1080 D=192, 8 pairs per call, ms per pair: 10.7 (0), 9.66-9.76 (1), 9.61-9.66 (2) -- the third
 // stream buys 1 % for a second AD-Census handle (3.3 GB) and a second crossarm handle, hence the default.
 #include "smt_common.h"
@@ -112,7 +112,7 @@ SMT_API int smt_pipeline_create(int H, int W, int D, const smt_pipeline_params *
         if (rc == SMT_OK) rc = smt_malloc((void **)&h->Rf[k], N * 4);
     }
     if (rc == SMT_OK) rc = smt_crossarm_create(H, W, D, &cp, &h->caL);
-    if (rc == SMT_OK && h->sched == 2) rc = smt_crossarm_create(H, W, D, &cp, &h->caR);
+    if (rc == SMT_OK && h->sched >= 1) rc = smt_crossarm_create(H, W, D, &cp, &h->caR);
     if (rc == SMT_OK) rc = smt_scanline_create(H, W, D, h->P.p1, h->P.p2, &h->so);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->agg[0], V * 4);
     if (rc == SMT_OK) rc = smt_malloc((void **)&h->agg[1], V * 4);
@@ -166,13 +166,14 @@ static int pipeline_run_simple(smt_pipeline *h, const uint8_t *grayL, const uint
         float *dl = dispL + b * N, *dr = dispR + b * N;
         int rc = SMT_OK;
         if (two) {
-            // the left view's arms need only the image: on the side stream (behind the previous pair's right view,
-            // which used the same handle) beside this pair's AD-Census
+            // both views' arms need only the images: on the side stream (the right view has its own handle), beside
+            // this pair's AD-Census
             rc = smt_crossarm_set_stream(h->caL, (void *)h->side);
             if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, L8, 1);                   // :67-72
             PIPE_HIP(hipEventRecord(h->ev_front[0], h->side));
             const int rc2 = smt_crossarm_set_stream(h->caL, st);
             if (rc == SMT_OK) rc = rc2;
+            if (rc == SMT_OK) rc = smt_crossarm_arms(h->caR, R8, 1);                   // :77-81 (its own Initialize: threshold reset)
         }
         if (rc == SMT_OK) rc = smt_u8_to_f32(L8, H, W, h->Lf[0], st);                   // main.cpp:46-55
         if (rc == SMT_OK) rc = smt_u8_to_f32(R8, H, W, h->Rf[0], st);
@@ -186,14 +187,11 @@ static int pipeline_run_simple(smt_pipeline *h, const uint8_t *grayL, const uint
         if (two) {
             PIPE_HIP(hipEventRecord(h->ev_left, h->stream));
             PIPE_HIP(hipStreamWaitEvent(h->side, h->ev_left, 0));
-            if (rc == SMT_OK) rc = smt_crossarm_set_stream(h->caL, (void *)h->side);
-        }
-        if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, R8, 1);                       // :77-81 (Initialize again: threshold reset)
-        if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->caL, vol[1], h->agg[1], 0, dr);       // :82-84
-        if (two) {
+            if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->caR, vol[1], h->agg[1], 0, dr);   // :82-84, beside the scanline
             PIPE_HIP(hipEventRecord(h->ev_right[0], h->side));
-            const int rc2 = smt_crossarm_set_stream(h->caL, st);                       // back, whatever happened
-            if (rc == SMT_OK) rc = rc2;
+        } else {
+            if (rc == SMT_OK) rc = smt_crossarm_arms(h->caL, R8, 1);                   // :77-81 (Initialize again: threshold reset)
+            if (rc == SMT_OK) rc = smt_crossarm_aggregate(h->caL, vol[1], h->agg[1], 0, dr);   // :82-84
         }
         if (rc == SMT_OK) rc = smt_scanline_run(h->so, h->agg[0], h->Lf[0], h->sovol, dl);     // :86-89
         if (two) PIPE_HIP(hipStreamWaitEvent(h->stream, h->ev_right[0], 0));
