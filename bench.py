@@ -3,9 +3,11 @@
 
 python bench.py --gpus N --steps K --warmup W
 One process per GPU (torch.distributed over RCCL when N > 1); pairs are independent, so each rank runs
-its own pairs with no data-path collective (weak scaling); config 5's only exchange -- one all_gather of
-the disparity maps + a checksum all_reduce (shard.py) -- sits at the end of the timed region unless
---no-gather is given, and is also timed by itself (extra.gather_ms).
+its own pairs with no data-path collective (weak scaling).  Config 5's only exchange -- one all_gather of
+the disparity maps + a checksum all_reduce (shard.py) -- sits at the end of the timed region for the batched
+workload (adcensus_kitti_d256; --gather forces it for any workload, --no-gather removes it); for the other
+workloads it runs after the region.  Either way it is timed by itself (extra.gather_ms) and the rate with / without
+it is reported.
 A step is one smt_adcensus_compute_batch call over --pairs-per-step (default 8) resident pairs: the steady-state
 throughput configuration (from the second pair of a batch on, the table kernels of the next pair overlap the
 cost kernel of the current one); the latency of a lone pair is reported beside it (ms_single_pair_call).
@@ -279,6 +281,9 @@ def main():
                          "of a batch on, the table kernels of pair n+1 overlap the cost kernel of pair n")
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the disparity gather out of the timed region")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: put the disparity gather inside the timed region for any workload (default: only for "
+                         "adcensus_kitti_d256, the batched configuration whose results are collected)")
     ap.add_argument("--no-extras", action="store_true", help="skip extra.configs (configs 1-5 after the timed region)")
     args = ap.parse_args()
 
@@ -318,6 +323,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The pair axis shards with no data-path collective.  The batched configuration (configs[4]) ends with one exchange
+    # -- all_gather of the disparity maps + a checksum all_reduce (shard.py) -- which belongs to its timed region; for
+    # the other workloads the same exchange is run and timed after the region and reported beside `value`.
+    gather_in_region = dist.is_initialized() and not args.no_gather and (args.gather or args.workload == "adcensus_kitti_d256")
     for _ in range(args.warmup):
         step()
     if dist.is_initialized() and not args.no_gather and args.warmup > 0:
@@ -333,17 +342,23 @@ def main():
     for _ in range(args.steps):
         step()
     gather_ms = None
-    if dist.is_initialized() and not args.no_gather:
-        # config 5's only exchange: gather the disparity maps, all-reduce a checksum (shard.py).  The
-        # synchronize in front only separates the two clocks; the barrier below would wait for it anyway.
+
+    def timed_gather():
+        # the synchronize in front only separates the two clocks; a barrier would wait for it anyway
         torch.cuda.synchronize()
         tg = time.perf_counter()
         shard.gather_disparities(dl, world * P)
         shard.checksum(dl)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
+        return (time.perf_counter() - tg) * 1e3
+
+    if gather_in_region:
+        gather_ms = timed_gather()
     barrier()
     dt = time.perf_counter() - t0
+    if dist.is_initialized() and not args.no_gather and not gather_in_region:
+        gather_ms = timed_gather()                        # outside the region: reported, not part of `value`
+        barrier()
     prep_ms, cost_ms = adc.kernel_times()
     adc.timing(False)
     adc.status()
@@ -413,13 +428,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"AD-Census 9x7 both views + WTA, {W}x{H} D={D} ({args.workload})",
                        "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)",
-                       "gather_in_timed_region": bool(dist.is_initialized() and not args.no_gather)},
+                       "gather_in_timed_region": bool(gather_in_region)},
             "roofline": roof,
         }
         extra = {}
         if gather_ms is not None:
             extra["gather_ms"] = round(gather_ms, 3)
-            extra["value_without_gather"] = round(total_pairs * hyp_pair / (dt - gather_ms * 1e-3) / 1e6, 2)
+            if gather_in_region:
+                extra["value_without_gather"] = round(total_pairs * hyp_pair / (dt - gather_ms * 1e-3) / 1e6, 2)
+            else:
+                extra["value_with_gather"] = round(total_pairs * hyp_pair / (dt + gather_ms * 1e-3) / 1e6, 2)
         if world == 1 and not args.no_extras:
             try:
                 extra["configs"] = extra_configs(dev)
