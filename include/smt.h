@@ -490,6 +490,17 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
  * 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
  * All produce identical bits. */
 int smt_asw_set_impl(int impl);
+/* Batch variants of the three window matchers ("batch variants taking a pair count and strides"):
+ * `pairs` image pairs and maps, consecutive pairs `img_stride` / `disp_stride` ELEMENTS apart (0 = dense: one
+ * padded image, (H+2w)*(W+2w) bytes for SAD / ASW and H*W for NCC; one map, H*W).  Exactly the results of
+ * `pairs` single calls, enqueued on `stream`; the per-call scratch of NCC / ASW is reused from pair to pair. */
+int smt_sad_batch(const uint8_t *Lp, const uint8_t *Rp, int pairs, size_t img_stride, int H, int W, int D, int winsize,
+                  int view, int32_t *disp, size_t disp_stride, void *stream);
+int smt_ncc_batch(const uint8_t *L, const uint8_t *R, int pairs, size_t img_stride, int H, int W, int D, int winSize,
+                  int32_t *disp, size_t disp_stride, void *stream);
+int smt_asw_batch(const uint8_t *Lp, const uint8_t *Rp, int pairs, size_t img_stride, int H, int W, int D, int winSize,
+                  const double *space, const double *color, int T, int view, float *disp, size_t disp_stride,
+                  void *stream);
 /* CrossCheckDiaparity (ASW.h:108-145): float maps -> uint8 map, 0 = rejected. */
 int smt_asw_crosscheck(const float *dispL, const float *dispR, int H, int W, uint8_t *out,
                        void *stream);

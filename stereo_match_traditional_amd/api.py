@@ -14,7 +14,7 @@ from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "costAggregationNew", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "ncc_set_impl", "asw_masks",
-           "AdaptiveSupportWeight", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
+           "AdaptiveSupportWeight", "sad_batch", "ncc_batch", "asw_batch", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
            "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline"]
 
 
@@ -654,6 +654,45 @@ def AdaptiveSupportWeight(leftGray, rightGray, winSize, dispRange, space, color,
     check(lib().smt_asw(_ptr(leftGray), _ptr(rightGray), H, W, dispRange, winSize, _ptr(space), _ptr(color), int(T),
                         view, _ptr(disp), _ptr(cost), current_stream_ptr()), "smt_asw")
     return (disp, cost) if want_cost else disp
+
+
+def sad_batch(leftimgs, rightimgs, MaxDisparity, winsize, view=VIEW_LEFT):
+    """smt_sad_batch: [P, H+2w, W+2w] uint8 padded pairs -> int32 [P, H, W] (GetPointDepthLeft / Right per pair)."""
+    w = winsize + 1
+    P, Hp, Wp = leftimgs.shape
+    H, W = Hp - 2 * w, Wp - 2 * w
+    _dev(leftimgs, torch.uint8, (P, Hp, Wp), "leftimgs")
+    _dev(rightimgs, torch.uint8, (P, Hp, Wp), "rightimgs")
+    disp = torch.empty((P, H, W), dtype=torch.int32, device=leftimgs.device)
+    check(lib().smt_sad_batch(_ptr(leftimgs), _ptr(rightimgs), P, C.c_size_t(0), H, W, MaxDisparity, winsize, view,
+                              _ptr(disp), C.c_size_t(0), current_stream_ptr()), "smt_sad_batch")
+    return disp
+
+
+def ncc_batch(leftImages, rightImages, winSize, dispRange):
+    """smt_ncc_batch: [P, H, W] uint8 pairs -> int32 [P, H, W] (NCC_algorithem per pair)."""
+    P, H, W = leftImages.shape
+    _dev(leftImages, torch.uint8, (P, H, W), "leftImages")
+    _dev(rightImages, torch.uint8, (P, H, W), "rightImages")
+    disp = torch.empty((P, H, W), dtype=torch.int32, device=leftImages.device)
+    check(lib().smt_ncc_batch(_ptr(leftImages), _ptr(rightImages), P, C.c_size_t(0), H, W, dispRange, winSize, _ptr(disp),
+                              C.c_size_t(0), current_stream_ptr()), "smt_ncc_batch")
+    return disp
+
+
+def asw_batch(leftGrays, rightGrays, winSize, dispRange, space, color, T, view=VIEW_LEFT):
+    """smt_asw_batch: [P, H+2w, W+2w] uint8 padded pairs -> float32 [P, H, W] (AdaptiveSupportWeight per pair)."""
+    wins = winSize + 1
+    P, Hp, Wp = leftGrays.shape
+    H, W = Hp - 2 * wins, Wp - 2 * wins
+    _dev(leftGrays, torch.uint8, (P, Hp, Wp), "leftGrays")
+    _dev(rightGrays, torch.uint8, (P, Hp, Wp), "rightGrays")
+    _dev(space, torch.float64, (2 * winSize + 3, 2 * winSize + 3), "space")
+    _dev(color, torch.float64, (256,), "color")
+    disp = torch.empty((P, H, W), dtype=torch.float32, device=leftGrays.device)
+    check(lib().smt_asw_batch(_ptr(leftGrays), _ptr(rightGrays), P, C.c_size_t(0), H, W, dispRange, winSize, _ptr(space),
+                              _ptr(color), int(T), view, _ptr(disp), C.c_size_t(0), current_stream_ptr()), "smt_asw_batch")
+    return disp
 
 
 def asw_set_impl(impl):

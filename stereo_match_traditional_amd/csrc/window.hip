@@ -894,3 +894,43 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }
+
+// ---- batch variants: the single-pair entry points pair by pair on the caller's stream --------------
+SMT_API int smt_sad_batch(const uint8_t *Lp, const uint8_t *Rp, int pairs, size_t img_stride, int H, int W, int D,
+                          int winsize, int view, int32_t *disp, size_t disp_stride, void *stream)
+{
+    if (!Lp || !Rp || !disp || pairs <= 0 || H <= 0 || W <= 0 || winsize < 0) return SMT_ERR_ARG;
+    const size_t w = (size_t)winsize + 1;
+    const size_t is = img_stride ? img_stride : ((size_t)H + 2 * w) * ((size_t)W + 2 * w), ds = disp_stride ? disp_stride : (size_t)H * W;
+    for (int b = 0; b < pairs; b++) {
+        const int rc = smt_sad(Lp + b * is, Rp + b * is, H, W, D, winsize, view, disp + b * ds, stream);
+        if (rc != SMT_OK) return rc;
+    }
+    return SMT_OK;
+}
+
+SMT_API int smt_ncc_batch(const uint8_t *L, const uint8_t *R, int pairs, size_t img_stride, int H, int W, int D, int winSize,
+                          int32_t *disp, size_t disp_stride, void *stream)
+{
+    if (!L || !R || !disp || pairs <= 0 || H <= 0 || W <= 0) return SMT_ERR_ARG;
+    const size_t is = img_stride ? img_stride : (size_t)H * W, ds = disp_stride ? disp_stride : (size_t)H * W;
+    for (int b = 0; b < pairs; b++) {
+        const int rc = smt_ncc(L + b * is, R + b * is, H, W, D, winSize, disp + b * ds, nullptr, stream);
+        if (rc != SMT_OK) return rc;
+    }
+    return SMT_OK;
+}
+
+SMT_API int smt_asw_batch(const uint8_t *Lp, const uint8_t *Rp, int pairs, size_t img_stride, int H, int W, int D, int winSize,
+                          const double *space, const double *color, int T, int view, float *disp, size_t disp_stride,
+                          void *stream)
+{
+    if (!Lp || !Rp || !disp || pairs <= 0 || H <= 0 || W <= 0 || winSize < 0) return SMT_ERR_ARG;
+    const size_t w = (size_t)winSize + 1;
+    const size_t is = img_stride ? img_stride : ((size_t)H + 2 * w) * ((size_t)W + 2 * w), ds = disp_stride ? disp_stride : (size_t)H * W;
+    for (int b = 0; b < pairs; b++) {
+        const int rc = smt_asw(Lp + b * is, Rp + b * is, H, W, D, winSize, space, color, T, view, disp + b * ds, nullptr, stream);
+        if (rc != SMT_OK) return rc;
+    }
+    return SMT_OK;
+}
