@@ -11,6 +11,12 @@ it is reported.
 A step is one smt_adcensus_compute_batch call over --pairs-per-step (default 8) resident pairs: the steady-state
 throughput configuration (from the second pair of a batch on, the table kernels of the next pair overlap the
 cost kernel of the current one); the latency of a lone pair is reported beside it (ms_single_pair_call).
+`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts its own N ranks: the parent --
+before anything touches the GPU -- spawns N children of this file with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would have set), relays rank 0's JSON line and exits
+non-zero if any child does.  Under a launcher (WORLD_SIZE set) nothing is spawned; a WORLD_SIZE that differs from
+--gpus is an error.  For every N the line also carries configs[4] as the strong-scaling case
+(extra.cfg5_kitti_256pairs_strong: 256 pairs in total, 256/N per rank, the gather inside its timed region).
 Prints ONE JSON line on rank 0.  After the timed region rank 0 also measures, outside `value`:
   roofline.sclk_mhz / store_ceiling_ms   in-kernel shader clock of the cost kernel and the same-run
                                          store-only ceiling of its store pattern (smt_adcensus_diag);
@@ -270,6 +276,111 @@ def extra_configs(dev, reps=5):
     return out
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher: be the launcher.  Nothing in this function touches the GPU
+    (torch.cuda.device_count() does not initialise it on this image) and nothing is exec'ed: N plain child
+    processes, one per GPU, with the rendezvous variables torch.distributed.run would have set."""
+    import socket
+    one_dev = os.environ.get("SMT_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_dev:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible (SMT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 "
+                         f"with a gloo rendezvous: a plumbing rehearsal, not a measurement)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 owns stdout (the ONE JSON line); anything the other ranks print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("SMT_BENCH_LAUNCH_TIMEOUT", "3000"))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+        if rc != 0 or time.time() > deadline:
+            # a dead rank leaves the others waiting in a collective: stop exactly the children started here
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(15)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def cfg5_strong(dev, world, rank, on_host, total=256, reps=3):
+    """BASELINE.json configs[4] as a strong-scaling case: 256 KITTI-size pairs (1242x375, D=256) in total,
+    shard.shard_range(256, N, rank) of them on this rank in ONE smt_adcensus_compute_batch call, then the path's
+    only exchange -- all_gather of the left maps + checksum all_reduce (shard.py) -- inside the timed region.
+    Timed like the headline: barrier + synchronize on both sides, MAX over ranks.  Every rank calls this."""
+    import torch.distributed as dist
+    import stereo_match_traditional_amd as smt
+    from stereo_match_traditional_amd import shard, synth
+    H, W, D = 375, 1242, 256
+    s, c = shard.shard_range(total, world, rank)
+    Ls, Rs = zip(*[synth.synth_pair(H, W, D, 1000 + b) for b in range(s, s + c)])
+    Lb = torch.from_numpy(np.stack(Ls).astype(np.float32)).to(dev)
+    Rb = torch.from_numpy(np.stack(Rs).astype(np.float32)).to(dev)
+    dl, dr = torch.empty((c, H, W), device=dev), torch.empty((c, H, W), device=dev)
+    adc = smt.AD_Census().Initialize(Lb[0], Rb[0], D, H, W, 10.0, 30.0)
+    multi = dist.is_initialized()
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def exchange():
+        src = dl.cpu() if on_host else dl
+        g = shard.gather_disparities(src, total)
+        return g, shard.checksum(src)
+
+    adc.ComputeBatch(Lb, Rb, dl, dr)                      # warm-up: kernels, RCCL channels of this shape
+    g, chk = exchange()
+    total_sum = float(g.double().sum())
+    t_all, t_gather = [], []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        adc.ComputeBatch(Lb, Rb, dl, dr)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        exchange()
+        barrier()
+        t2 = time.perf_counter()
+        t_all.append(t2 - t0)
+        t_gather.append(t2 - t1)
+    adc.status()
+    adc.close()
+    best = int(np.argmin(t_all))
+    tt = torch.tensor([t_all[best], t_gather[best]], dtype=torch.float64, device="cpu" if on_host else dev)
+    if multi:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t, tg = float(tt[0]), float(tt[1])
+    hyp = total * H * W * D
+    return {"pairs_total": total, "pairs_this_rank": c, "ranks": world, "scaling": "strong",
+            "ms_total_with_gather": round(t * 1e3, 3), "gather_ms": round(tg * 1e3, 3),
+            "value_with_gather": round(hyp / t / 1e6, 1), "value_without_gather": round(hyp / max(t - tg, 1e-9) / 1e6, 1),
+            "unit": "Mdisp/s", "ms_per_pair_with_gather": round(t / total * 1e3, 4),
+            "gathered_maps": list(g.shape), "checksum_allreduce_equals_sum_of_gathered": bool(abs(chk - total_sum) <= 1e-6 * max(1.0, abs(total_sum))),
+            "timing": f"best of {reps} repetitions, max over ranks, barrier + synchronize on both sides"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,18 +398,30 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip extra.configs (configs 1-5 after the timed region)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(sys.argv[1:], args.gpus)              # never returns; nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with "
-                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
+        raise SystemExit(f"WORLD_SIZE={world} is set but --gpus {args.gpus}: the launcher's world size and --gpus must agree "
+                         f"(without a launcher, plain `python bench.py --gpus {args.gpus}` starts its own ranks)")
     import torch.distributed as dist
+    # rehearsal mode for a one-GPU box: every rank on cuda:0, gloo rendezvous, collectives on host copies (RCCL
+    # refuses two ranks on one device).  The line says so (config.backend); it is not a scaling measurement.
+    one_dev = os.environ.get("SMT_BENCH_ONE_DEVICE") == "1" and world > 1
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # torch.distributed.run
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # torch.distributed.run or self_launch
+    backend = None
     if world > 1 or launched:
-        dist.init_process_group("nccl", device_id=dev)                   # RCCL on ROCm
+        backend = "gloo" if one_dev else "nccl"
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)               # RCCL on ROCm
 
     import stereo_match_traditional_amd as smt
     from stereo_match_traditional_amd import shard, synth
@@ -323,6 +446,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def xdl():
+        # what the exchange moves: the device maps over RCCL; host copies in the one-device gloo rehearsal
+        return dl.cpu() if one_dev else dl
+
     # The pair axis shards with no data-path collective.  The batched configuration (configs[4]) ends with one exchange
     # -- all_gather of the disparity maps + a checksum all_reduce (shard.py) -- which belongs to its timed region; for
     # the other workloads the same exchange is run and timed after the region and reported beside `value`.
@@ -331,8 +458,8 @@ def main():
         step()
     if dist.is_initialized() and not args.no_gather and args.warmup > 0:
         # part of the warm-up: the first collective of a shape sets up RCCL's channels (64 ms on one GPU)
-        shard.gather_disparities(dl, world * P)
-        shard.checksum(dl)
+        shard.gather_disparities(xdl(), world * P)
+        shard.checksum(xdl())
     barrier()
     # HIP events around the kernels of ~32 pairs spread over the run (each record costs ~3 us of stream time and
     # a timed pair carries four)
@@ -347,8 +474,8 @@ def main():
         # the synchronize in front only separates the two clocks; a barrier would wait for it anyway
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        shard.gather_disparities(dl, world * P)
-        shard.checksum(dl)
+        shard.gather_disparities(xdl(), world * P)
+        shard.checksum(xdl())
         torch.cuda.synchronize()
         return (time.perf_counter() - tg) * 1e3
 
@@ -363,10 +490,26 @@ def main():
     adc.timing(False)
     adc.status()
 
-    tt = torch.tensor([dt, gather_ms or 0.0], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, gather_ms or 0.0], dtype=torch.float64, device="cpu" if one_dev else dev)
     if dist.is_initialized():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, gather_ms = float(tt[0].item()), (float(tt[1].item()) if gather_ms is not None else None)
+    joined = 1
+    if dist.is_initialized():
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if one_dev else dev)
+        dist.all_reduce(ones)                                # SUM over the communicator: how many ranks really took part
+        joined = int(ones.item())
+
+    # configs[4] as the strong-scaling case: every rank takes part (256 pairs in total, gather inside)
+    strong = None
+    if not args.no_extras:
+        if world == 1:
+            try:
+                strong = cfg5_strong(dev, world, rank, one_dev)
+            except Exception as e:                           # never lose the headline line to an extra
+                strong = {"error": repr(e)}
+        else:
+            strong = cfg5_strong(dev, world, rank, one_dev)  # a rank that fails here ends the job: no silent hang
 
     # latency of a lone pair (one call, nothing to overlap with), outside the timed region
     single_ms = None
@@ -428,7 +571,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"AD-Census 9x7 both views + WTA, {W}x{H} D={D} ({args.workload})",
                        "pairs_per_step_per_gpu": P, "parallelism": f"pairs sharded over {world} GPU(s)",
-                       "gather_in_timed_region": bool(gather_in_region)},
+                       "gather_in_timed_region": bool(gather_in_region),
+                       "backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo, every rank on cuda:0 (SMT_BENCH_ONE_DEVICE rehearsal, "
+                                    "not a scaling measurement)"}[backend] if backend else "none (single process)"),
+                       "ranks_joined": joined, "ranks_joined_how": "all_reduce(SUM) of 1 per rank over the job's communicator",
+                       "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "launcher": ("self (bench.py spawned its ranks)" if os.environ.get("SMT_BENCH_SELF_LAUNCHED") == "1"
+                                    else ("external (WORLD_SIZE was set)" if launched else "none"))},
             "roofline": roof,
         }
         extra = {}
@@ -438,6 +587,8 @@ def main():
                 extra["value_without_gather"] = round(total_pairs * hyp_pair / (dt - gather_ms * 1e-3) / 1e6, 2)
             else:
                 extra["value_with_gather"] = round(total_pairs * hyp_pair / (dt + gather_ms * 1e-3) / 1e6, 2)
+        if strong is not None:
+            extra["cfg5_kitti_256pairs_strong"] = strong
         if world == 1 and not args.no_extras:
             try:
                 extra["configs"] = extra_configs(dev)
