@@ -484,9 +484,21 @@ int smt_asw_masks(int winSize, double sigma_space, double sigma_color, double *s
 int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSize,
             const double *space, const double *color, int T, int view, float *disp, float *cost,
             void *stream);
+/* Scratch device memory of smt_asw / smt_ncc comes from an arena the library owns (csrc/scratch.hip: hipMalloc'ed
+ * blocks cached per device and handed out stream-ordered on the caller's stream).  The arena keeps what it has grown
+ * to -- the anchor table of an smt_asw call, 24*H*W bytes after an smt_ncc -- until the process ends or the host asks
+ * for it back: smt_scratch_trim synchronises the current device and returns every idle block beyond `keep_bytes` to
+ * the driver (hipFree); smt_scratch_info reports what the arena holds / has handed out.
+ * Why not hipMallocAsync: on ROCm 7.2 a stream-ordered pool that trims and grows again hands out a block that is
+ * zero-filled while the kernels already run on it (wrong ASW maps in round 2; tools/asw_bisect.py).
+ * SMT_SCRATCH_MODE=pool|default|malloc (environment, for that tool) selects a never-trimming hipMemPool / the
+ * device's default pool (the failing configuration) / plain hipMalloc per call. */
+int smt_scratch_trim(size_t keep_bytes);
+int smt_scratch_info(size_t *reserved_bytes, size_t *used_bytes);
 /* Test hook (process-wide): 3 = anchor-weight table + per-row other-image weight tables in LDS (default; needs
  * H*W*(2*winSize+3)^2*8 bytes of scratch device memory for the duration of the call, stream-ordered; a wave
- * carries two pixels), 4 = the same with one pixel per wave,
+ * carries two pixels), 4 = the same with one pixel per wave, 5 = as 3 with the anchor operands read by vector
+ * loads instead of through the scalar cache,
  * 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
  * All produce identical bits. */
 int smt_asw_set_impl(int impl);

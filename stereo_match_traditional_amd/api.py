@@ -15,11 +15,29 @@ __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "choose
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
            "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "ncc_set_impl", "asw_masks",
            "AdaptiveSupportWeight", "sad_batch", "ncc_batch", "asw_batch", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
-           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline"]
+           "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline", "scratch_trim", "scratch_info"]
 
 
-def current_stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def current_stream_ptr(device=None):
+    """torch's current stream on `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _on_tensor_device(f):
+    """Stateless entry points launch on the current HIP device: make the device of the first tensor argument current
+    for the call (a no-op on a one-GPU process), so that the kernels and the stream belong to the tensors' GPU."""
+    import functools
+
+    @functools.wraps(f)
+    def g(*a, **kw):
+        for t in list(a) + list(kw.values()):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                if t.device.index is not None and t.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(t.device):
+                        return f(*a, **kw)
+                break
+        return f(*a, **kw)
+    return g
 
 
 def _ptr(t):
@@ -34,6 +52,14 @@ def _dev(t, dtype, shape=None, name="tensor"):
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
     return t
+
+
+def _dev_index(device):
+    """HIP device ordinal of a torch device (cuda without an index = the current one)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise TypeError(f"{device} is not a GPU")
+    return torch.cuda.current_device() if device.index is None else int(device.index)
 
 
 def _view_of(base_ptr, shape, dtype, device):
@@ -70,14 +96,16 @@ class AD_Census:
         self._R = _dev(rightImage, torch.float32, (row, col), "rightImage")
         self.device = leftImage.device
         h = C.c_void_p()
-        check(lib().smt_adcensus_create(self.row, self.col, self.dispRange, C.c_float(sigmaC),
-                                        C.c_float(sigmaS), C.byref(h)), "smt_adcensus_create")
+        if rightImage.device != self.device:
+            raise ValueError("leftImage and rightImage live on different devices")
+        check(lib().smt_adcensus_create_on(_dev_index(self.device), self.row, self.col, self.dispRange, C.c_float(sigmaC),
+                                           C.c_float(sigmaS), C.byref(h)), "smt_adcensus_create_on")
         self._h = h
         self._views = 0
         return self
 
     def _bind_stream(self):
-        check(lib().smt_adcensus_set_stream(self._h, current_stream_ptr()), "smt_adcensus_set_stream")
+        check(lib().smt_adcensus_set_stream(self._h, current_stream_ptr(self.device)), "smt_adcensus_set_stream")
 
     def _compute(self, views, dispL=None, dispR=None):
         self._bind_stream()
@@ -181,6 +209,7 @@ class AD_Census:
             pass
 
 
+@_on_tensor_device
 def wta(vol, disp=None):
     """First-strict-minimum argmin over d (CrossArm.cpp:33-57, ScanlineOptimizer.h:40-64,
     CBLSM.h:383-407)."""
@@ -219,13 +248,13 @@ class CrossArmAggregation:
         if quirks is not None:
             p.quirks = quirks
         h = C.c_void_p()
-        check(lib().smt_crossarm_create(self.row, self.col, self.dispRange, C.byref(p), C.byref(h)),
-              "smt_crossarm_create")
+        check(lib().smt_crossarm_create_on(_dev_index(self.device), self.row, self.col, self.dispRange, C.byref(p), C.byref(h)),
+              "smt_crossarm_create_on")
         self._h = h
         return self
 
     def _bind(self):
-        check(lib().smt_crossarm_set_stream(self._h, current_stream_ptr()), "smt_crossarm_set_stream")
+        check(lib().smt_crossarm_set_stream(self._h, current_stream_ptr(self.device)), "smt_crossarm_set_stream")
 
     def ComputeArmLengths(self, Image):
         """ComputeLeftArmLength, ComputeRightArmLength, ComputeTopArmLength,
@@ -332,6 +361,7 @@ class CrossArmAggregation:
             pass
 
 
+@_on_tensor_device
 def cblsm_ComputeAD(L, R, dispRange, view=VIEW_LEFT, out=None):
     """CBLSM.h:327-353 (view left) / :355-381 (view right): uchar images -> float AD volume."""
     H, W = L.shape
@@ -344,6 +374,7 @@ def cblsm_ComputeAD(L, R, dispRange, view=VIEW_LEFT, out=None):
     return out
 
 
+@_on_tensor_device
 def _choose_arm(dirn, own, vert, ArmRL, ArmRR, dispRange, Armvolume, row, col):
     for a in (own, vert, ArmRL, ArmRR):
         if a is not None:
@@ -377,6 +408,7 @@ def chooseArmLengthDown(ArmLUp, ArmLDown, ArmRUp, ArmRDown, ArmRL, ArmRR, dispRa
     return _choose_arm(3, ArmLDown, ArmRDown, ArmRL, ArmRR, dispRange, Armvolume, row, col)
 
 
+@_on_tensor_device
 def costAggregationNew(leftImage, rightImage, CostVolume, ArmvolumeL, ArmvolumeR, ArmvolumeUp, ArmvolumeDown, dispRange,
                        _row_, _col_, winSize):
     """CBLSM.h:1087-1126 (argument order of the reference).  Padded uint8 images, int32 [row][col][D] arm
@@ -408,8 +440,8 @@ class ScanlineOptimizer:
         self.row, self.col, self.dispRange = int(row), int(col), int(dispRange)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         h = C.c_void_p()
-        check(lib().smt_scanline_create(self.row, self.col, self.dispRange, int(p1), int(p2), C.byref(h)),
-              "smt_scanline_create")
+        check(lib().smt_scanline_create_on(_dev_index(self.device), self.row, self.col, self.dispRange, int(p1), int(p2), C.byref(h)),
+              "smt_scanline_create_on")
         self._h = h
         self._processed = None
         return self
@@ -422,7 +454,7 @@ class ScanlineOptimizer:
         if out is None:
             out = torch.empty(shp, dtype=torch.float32, device=costVolume.device)
         _dev(out, torch.float32, shp, "out")
-        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr()), "smt_scanline_set_stream")
+        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr(self.device)), "smt_scanline_set_stream")
         check(lib().smt_scanline_run(self._h, _ptr(costVolume), _ptr(Image), _ptr(out), _ptr(disp)),
               "smt_scanline_run")
         self._processed = out
@@ -433,7 +465,7 @@ class ScanlineOptimizer:
         (ScanLineUpDown isUp=true, :194-253), 'down'."""
         pass_id = {"left": 0, "right": 1, "up": 2, "down": 3}[which]
         out = torch.empty_like(costVolume)
-        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr()), "smt_scanline_set_stream")
+        check(lib().smt_scanline_set_stream(self._h, current_stream_ptr(self.device)), "smt_scanline_set_stream")
         check(lib().smt_scanline_pass(self._h, _ptr(costVolume), _ptr(Image), pass_id, _ptr(out)),
               "smt_scanline_pass")
         return out
@@ -457,6 +489,7 @@ class ScanlineOptimizer:
 # ======================================================================================
 # LeftRightConsistency  (AD-CensusV1/PostProcessing.h:72-135)
 # ======================================================================================
+@_on_tensor_device
 def LeftRightConsistency(col, row, gate, leftDisp, rightDisp, want_lists=False):
     """In place on leftDisp (+inf = invalid).  Returns (cls uint8 [row][col], n_occlusion,
     n_mismatch[, occlusions, mismatches]); the lists are (row, col) pairs in the
@@ -480,6 +513,7 @@ def LeftRightConsistency(col, row, gate, leftDisp, rightDisp, want_lists=False):
     return cls, n[0], n[1], occ[:no.value], mis[:nm.value]
 
 
+@_on_tensor_device
 def LeftAndRightConsistency(leftDisp, rightDisp, lastDisp, col, row, gate):
     """PostProcessing.h:10-70 (argument order of the reference; no call site there): out of place, lastDisp
     receives the kept disparities and 0 for rejected pixels.  Returns (cls, n_occlusion, n_mismatch)."""
@@ -494,6 +528,7 @@ def LeftAndRightConsistency(leftDisp, rightDisp, lastDisp, col, row, gate):
     return cls, n[0], n[1]
 
 
+@_on_tensor_device
 def FillTheHole(row, col, dispRange, dispLeft, occlusion, mismatch):
     """PostProcessing.h:156-248, in place on the device map dispLeft ([row][col] float32; the
     reference's internal width/height swap is reproduced).  occlusion / mismatch: (first, second)
@@ -526,7 +561,7 @@ class CrossAggregator:
         self.disp_range = int(max_disparity) - int(min_disparity)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         h = C.c_void_p()
-        rc = lib().smt_crossagg_create(self.width, self.height, self.disp_range, C.byref(h))
+        rc = lib().smt_crossagg_create_on(_dev_index(self.device), self.width, self.height, self.disp_range, C.byref(h))
         if rc == -1:
             return False
         check(rc, "smt_crossagg_create")
@@ -546,7 +581,7 @@ class CrossAggregator:
         """:89-118; silently does nothing when uninitialised, like the reference (:91-93)."""
         if self._h is None:
             return
-        check(lib().smt_crossagg_set_stream(self._h, current_stream_ptr()), "smt_crossagg_set_stream")
+        check(lib().smt_crossagg_set_stream(self._h, current_stream_ptr(self.device)), "smt_crossagg_set_stream")
         check(lib().smt_crossagg_aggregate(self._h, _ptr(self._img), _ptr(self._cost), int(num_iters)),
               "smt_crossagg_aggregate")
 
@@ -589,6 +624,7 @@ def GetPointDepthRight(leftimg, rightimg, MaxDisparity, winsize):
     return _sad(leftimg, rightimg, MaxDisparity, winsize, VIEW_RIGHT)
 
 
+@_on_tensor_device
 def _sad(Lp, Rp, D, winsize, view):
     w = winsize + 1
     Hp, Wp = Lp.shape
@@ -600,6 +636,7 @@ def _sad(Lp, Rp, D, winsize, view):
     return disp
 
 
+@_on_tensor_device
 def sad_CrossCheckDiaparity(leftdisp, rightdisp):
     """Sad.h:184-222 -> (lastdisp int32, cls uint8)."""
     H, W = leftdisp.shape
@@ -612,6 +649,7 @@ def sad_CrossCheckDiaparity(leftdisp, rightdisp):
     return out, cls
 
 
+@_on_tensor_device
 def NCC_algorithem(leftImage, rigthImage, winSize, dispRange, want_cost=False):
     """NCC.h:69-95.  uint8 [H][W] unpadded images -> int32 disparity (argmax)."""
     H, W = leftImage.shape
@@ -640,6 +678,7 @@ def asw_masks(winSize, spaceSigma, colorSigma, device):
     return torch.from_numpy(sp).to(device), torch.from_numpy(cm).to(device)
 
 
+@_on_tensor_device
 def AdaptiveSupportWeight(leftGray, rightGray, winSize, dispRange, space, color, T, view=VIEW_LEFT, want_cost=False):
     """ASW.h:329-378 (view left) / :382-431 (view right).  Padded uint8 images."""
     wins = winSize + 1
@@ -656,6 +695,7 @@ def AdaptiveSupportWeight(leftGray, rightGray, winSize, dispRange, space, color,
     return (disp, cost) if want_cost else disp
 
 
+@_on_tensor_device
 def sad_batch(leftimgs, rightimgs, MaxDisparity, winsize, view=VIEW_LEFT):
     """smt_sad_batch: [P, H+2w, W+2w] uint8 padded pairs -> int32 [P, H, W] (GetPointDepthLeft / Right per pair)."""
     w = winsize + 1
@@ -669,6 +709,7 @@ def sad_batch(leftimgs, rightimgs, MaxDisparity, winsize, view=VIEW_LEFT):
     return disp
 
 
+@_on_tensor_device
 def ncc_batch(leftImages, rightImages, winSize, dispRange):
     """smt_ncc_batch: [P, H, W] uint8 pairs -> int32 [P, H, W] (NCC_algorithem per pair)."""
     P, H, W = leftImages.shape
@@ -680,6 +721,7 @@ def ncc_batch(leftImages, rightImages, winSize, dispRange):
     return disp
 
 
+@_on_tensor_device
 def asw_batch(leftGrays, rightGrays, winSize, dispRange, space, color, T, view=VIEW_LEFT):
     """smt_asw_batch: [P, H+2w, W+2w] uint8 padded pairs -> float32 [P, H, W] (AdaptiveSupportWeight per pair)."""
     wins = winSize + 1
@@ -700,6 +742,7 @@ def asw_set_impl(impl):
     check(lib().smt_asw_set_impl(int(impl)), "smt_asw_set_impl")
 
 
+@_on_tensor_device
 def asw_CrossCheckDiaparity(leftdisp, rightdisp):
     """ASW.h:108-145 -> uint8 map (0 = rejected)."""
     H, W = leftdisp.shape
@@ -714,6 +757,7 @@ def asw_CrossCheckDiaparity(leftdisp, rightdisp):
 # ======================================================================================
 # Either side of the path: input staging and the first post-filter
 # ======================================================================================
+@_on_tensor_device
 def cvtColor_BGR2GRAY(bgr):
     """cvtColor(img, gray, CV_BGR2GRAY) (main.cpp:19-20); uint8 [H][W][3] -> uint8 [H][W]."""
     H, W, _ = bgr.shape
@@ -723,6 +767,7 @@ def cvtColor_BGR2GRAY(bgr):
     return gray
 
 
+@_on_tensor_device
 def copyMakeBorder_replicate(img, pad):
     """copyMakeBorder(img, out, pad, pad, pad, pad, BORDER_REPLICATE) (SADmain.cpp:47-48)."""
     H, W = img.shape
@@ -732,6 +777,7 @@ def copyMakeBorder_replicate(img, pad):
     return out
 
 
+@_on_tensor_device
 def to_float(img):
     """uchar -> float copy of main.cpp:46-55."""
     H, W = img.shape
@@ -741,6 +787,7 @@ def to_float(img):
     return out
 
 
+@_on_tensor_device
 def MedianFilter(inp, width, height, wnd_size):
     """PostProcessing.h:314-344."""
     _dev(inp, torch.float32, (height, width), "in")
@@ -750,6 +797,7 @@ def MedianFilter(inp, width, height, wnd_size):
     return out
 
 
+@_on_tensor_device
 def RemoveSpeckles(disparity_map, width, height, diff_insame, min_speckle_aera, invalid_val):
     """PostProcessing.h:250-311, in place.  invalid_val: int, as in the reference's signature."""
     _dev(disparity_map, torch.float32, (height, width), "disparity_map")
@@ -800,6 +848,7 @@ def ADCensusOption(**overrides):
     return o
 
 
+@_on_tensor_device
 def adcensus_option_aggregate(option, bytes_left, dispVolum, num_iters=4, want_disp=True):
     """CBLSM.cpp:138-143 + :152: CrossAggregator driven by an ADCensusOption -> (cost, disp)."""
     H, W, _ = bytes_left.shape
@@ -816,6 +865,20 @@ def adcensus_option_aggregate(option, bytes_left, dispVolum, num_iters=4, want_d
 # ======================================================================================
 # The whole AD-CensusV1/main.cpp pipeline, batched (smt_pipeline_*)
 # ======================================================================================
+def scratch_trim(keep_bytes=0, device=None):
+    """smt_scratch_trim on `device` (default: current): idle scratch of smt_asw / smt_ncc back to the driver."""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib().smt_scratch_trim(C.c_size_t(int(keep_bytes))), "smt_scratch_trim")
+
+
+def scratch_info(device=None):
+    """(reserved_bytes, used_bytes) of the library's scratch arena on `device`."""
+    r, u = C.c_size_t(0), C.c_size_t(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib().smt_scratch_info(C.byref(r), C.byref(u)), "smt_scratch_info")
+    return int(r.value), int(u.value)
+
+
 class Pipeline:
     """main.cpp:46-92 (scanline and LR check enabled) for batches of gray pairs; the sharding unit of config 3."""
 
@@ -829,7 +892,8 @@ class Pipeline:
                 raise AttributeError(k)
             setattr(p, k, v)
         h = C.c_void_p()
-        check(lib().smt_pipeline_create(self.row, self.col, self.dispRange, C.byref(p), C.byref(h)), "smt_pipeline_create")
+        check(lib().smt_pipeline_create_on(_dev_index(self.device), self.row, self.col, self.dispRange, C.byref(p), C.byref(h)),
+              "smt_pipeline_create_on")
         self._h = h
 
     def run(self, grayL, grayR):
@@ -837,13 +901,15 @@ class Pipeline:
         if grayL.dim() == 2:
             grayL, grayR = grayL[None], grayR[None]
         P = grayL.shape[0]
+        if _dev_index(grayL.device) != _dev_index(self.device) or grayR.device != grayL.device:
+            raise ValueError(f"pipeline handle lives on {self.device}, images on {grayL.device} / {grayR.device}")
         _dev(grayL, torch.uint8, (P, self.row, self.col), "grayL")
         _dev(grayR, torch.uint8, (P, self.row, self.col), "grayR")
         dl = torch.empty((P, self.row, self.col), dtype=torch.float32, device=grayL.device)
         dr = torch.empty_like(dl)
         cls = torch.empty((P, self.row, self.col), dtype=torch.uint8, device=grayL.device)
         counts = torch.zeros((P, 2), dtype=torch.int32, device=grayL.device)
-        check(lib().smt_pipeline_set_stream(self._h, current_stream_ptr()), "smt_pipeline_set_stream")
+        check(lib().smt_pipeline_set_stream(self._h, current_stream_ptr(self.device)), "smt_pipeline_set_stream")
         check(lib().smt_pipeline_run_batch(self._h, _ptr(grayL), _ptr(grayR), P, _ptr(dl), _ptr(dr), _ptr(cls), _ptr(counts)),
               "smt_pipeline_run_batch")
         return dl, dr, cls, counts

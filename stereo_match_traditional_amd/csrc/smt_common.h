@@ -44,36 +44,10 @@ struct smt_dev_guard {
 };
 static inline int smt_current_device() { int d = -1; return hipGetDevice(&d) == hipSuccess ? d : -1; }
 
-// Stream-ordered scratch for smt_asw and smt_ncc (tables that live for one call): allocated from a memory pool the
-// library owns, one per device, created with the release threshold at its maximum so that the pool never hands
-// memory back between calls.  Not the device's default pool: with its default threshold (0) the pool trims at every
-// synchronisation, and a trim followed by a re-grow between two library calls gave wrong data in the first kernel
-// that used the re-grown block (ROCm 7.2, gfx950: the first smt_asw after an smt_ncc read garbage anchor weights
-// for runs of pixels; tools/ history in DESIGN.md).  Free with hipFreeAsync on the same stream.
-static inline hipError_t smt_scratch_alloc(void **p, size_t bytes, hipStream_t st)
-{
-    static hipMemPool_t pools[64] = {};
-    static std::mutex mu;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!pools[dev]) {
-        hipMemPoolProps props = {};
-        props.allocType = hipMemAllocationTypePinned;
-        props.handleTypes = hipMemHandleTypeNone;
-        props.location.type = hipMemLocationTypeDevice;
-        props.location.id = dev;
-        hipMemPool_t pool = nullptr;
-        e = hipMemPoolCreate(&pool, &props);
-        if (e != hipSuccess) return e;
-        unsigned long long keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        pools[dev] = pool;
-    }
-    return hipMallocFromPoolAsync(p, bytes, pools[dev], st);
-}
+// Stream-ordered scratch for smt_asw and smt_ncc (tables that live for one call): csrc/scratch.hip owns the one pool
+// set of the library.  Free with smt_scratch_free on the same stream.
+hipError_t smt_scratch_alloc(void **p, size_t bytes, hipStream_t st);
+void smt_scratch_free(void *p, hipStream_t st);
 
 #ifdef __HIPCC__
 constexpr int WAVE = 64;

@@ -12,6 +12,7 @@
 // 422-425) make cost[d] = cost[dmax] for d beyond the last in-range disparity dmax, i.e.
 // the hypothesis is evaluated at min(d, dmax).
 #include "smt_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -579,6 +580,42 @@ __global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ 
     }
 }
 
+// Diagnostic (SMT_ASW_VERIFY=1): recomputes every entry of the two anchor tables with the arithmetic of k_asw_anchor
+// and compares it with what memory holds, read with ordinary vector loads.  counts[0] = w0 entries that differ,
+// [1] = of those, entries that read as +0.0 (a cleared page), [2] = entries that read as NaN, [3] = a32 entries
+// that differ, [4] = first differing w0 index + 1 (atomicMin over a start value of ~0), [5] = last differing index + 1.
+__global__ void __launch_bounds__(256) k_asw_anchor_check(const uint8_t *__restrict__ Ap, int H, int W, int wins,
+                                                          const double *__restrict__ space, const double *__restrict__ color,
+                                                          const double *w0, const unsigned *a32, unsigned long long *counts)
+{
+    const int side = 2 * wins + 1, Wp = W + 2 * wins, Hp = H + 2 * wins;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Hp * Wp; k += (size_t)gridDim.x * 256)
+        if (a32[k] != __float_as_uint((float)Ap[k])) atomicAdd(&counts[3], 1ull);
+    const size_t p = (size_t)blockIdx.x * 4 + wv;
+    if (p >= (size_t)H * W) return;
+    const int io = (int)(p / W), jo = (int)(p % W);
+    const uint8_t *A = Ap + (size_t)io * Wp + jo;
+    const int ca = A[wins * Wp + wins];
+    const int ntap = side * side;
+    const double *in = w0 + p * ntap;
+    for (int t = lane; t < ntap; t += 64) {
+        const int r = t / side, c = t - r * side;
+        const int pa = A[r * Wp + c];
+        const double sp = space[t];
+        const double want = color[abs(pa - ca)] * (sp * sp);
+        const double got = in[t];
+        if (__double_as_longlong(got) != __double_as_longlong(want)) {
+            atomicAdd(&counts[0], 1ull);
+            if (__double_as_longlong(got) == 0) atomicAdd(&counts[1], 1ull);
+            if (got != got) atomicAdd(&counts[2], 1ull);
+            const unsigned long long idx = (unsigned long long)(p * ntap + t) + 1;
+            atomicMin(&counts[4], idx);
+            atomicMax(&counts[5], idx);
+        }
+    }
+}
+
 // One ds_read_b64 that stays one: the compiler would pair neighbouring columns into ds_read2_b64, which the LDS
 // serves at half the bytes per clock of ds_read_b64 (MI355X_MICROARCH.md, LDS table).
 __device__ __forceinline__ double lds_f64(const double *p)
@@ -596,7 +633,9 @@ __device__ __forceinline__ P uniform_ptr(P p)
 }
 
 // A3Q = pixels per wave: the per-row tables are built once for A3P * A3Q pixels
-template <int K, int A3Q>
+// SLOAD = false (smt_asw_set_impl(5)) reads the two anchor operands with ordinary vector loads from the same
+// wave-uniform addresses instead of s_load: same arithmetic, same results, one more formulation for bisecting.
+template <int K, int A3Q, bool SLOAD = true>
 __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
                                                    int W, int D, int wins, const double *__restrict__ color,
                                                    const double *__restrict__ w0, const unsigned *__restrict__ a32, int T,
@@ -675,9 +714,11 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
         for (int q = 0; q < A3Q; q++) {
             cdouble_p wr = uniform_ptr(wrow[q] + r * side);   // wave-uniform operands through the scalar cache
             cunsigned_p ar = uniform_ptr(arow[q] + (size_t)r * Wp);
+            const double *wrv = w0 + (((size_t)io * W + (live[q] ? jo[q] : W - 1)) * side + r) * side;
+            const unsigned *arv = a32 + ((size_t)io + r) * Wp + (live[q] ? jo[q] : W - 1);
             auto tap = [&](int c) {
-                const double w = wr[c];
-                const float pa = __uint_as_float(ar[c]);
+                const double w = SLOAD ? wr[c] : __builtin_nontemporal_load(wrv + c);
+                const float pa = __uint_as_float(SLOAD ? ar[c] : __builtin_nontemporal_load(arv + c));
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     const double c1 = lds_f64(tk[q][k] + c);
@@ -725,10 +766,10 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
 
 }  // namespace
 
-static int g_asw_impl = 3;   // 3: k_asw_anchor + k_asw3, two pixels per wave (default); 4: one pixel per wave; 1: k_asw (first formulation)
+static int g_asw_impl = 3;   // 3: k_asw_anchor + k_asw3, two pixels per wave (default); 4: one pixel per wave; 5: as 3 with vector loads of the anchor operands; 1: k_asw (first formulation)
 SMT_API int smt_asw_set_impl(int impl)
 {
-    if (impl != 1 && impl != 3 && impl != 4) return SMT_ERR_ARG;
+    if (impl != 1 && impl != 3 && impl != 4 && impl != 5) return SMT_ERR_ARG;
     g_asw_impl = impl;
     return SMT_OK;
 }
@@ -786,7 +827,7 @@ SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int
         int *sums = nullptr;
         double *roots = nullptr;
         if (smt_scratch_alloc((void **)&roots, (size_t)N * 8 * 2, st) == hipSuccess) {
-            if (smt_scratch_alloc((void **)&sums, (size_t)N * 4 * 2, st) != hipSuccess) { (void)hipFreeAsync(roots, st); return SMT_ERR_ALLOC; }
+            if (smt_scratch_alloc((void **)&sums, (size_t)N * 4 * 2, st) != hipSuccess) { smt_scratch_free(roots, st); return SMT_ERR_ALLOC; }
             const int RR = NCT + 2 * winSize, RC = 64 + 2 * winSize;
             const size_t shm1 = (((size_t)RR * RC + 15) & ~(size_t)15) + (size_t)RR * 64 * 8;
             hipLaunchKernelGGL(k_ncc_stats, dim3((Wi + 63) / 64, (Hi + NCT - 1) / NCT, 2), dim3(256), shm1, st, L, R, H, W, winSize,
@@ -802,8 +843,8 @@ SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int
             case 3: rc = launch_ncc2<3>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
             default: rc = launch_ncc2<4>(G, grid, shm2, st, L, R, H, W, D, winSize, sums, roots, sums + N, roots + N, RW, CS, disp, cost); break;
             }
-            (void)hipFreeAsync(sums, st);
-            (void)hipFreeAsync(roots, st);
+            smt_scratch_free(sums, st);
+            smt_scratch_free(roots, st);
             if (rc != SMT_OK) return rc;
             SMT_LAUNCH_CHECK();
             return SMT_OK;
@@ -840,8 +881,10 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     if (side > 64) return SMT_ERR_ARG;                   // one window row per wave pass
     const int N = H * W;
     const int v = view == SMT_VIEW_LEFT ? 0 : 1;
-    if (g_asw_impl >= 3 && side >= 5) {
-        const int A3Q = g_asw_impl == 4 ? 1 : 2;
+    static const int env_impl = [] { const char *e = getenv("SMT_ASW_IMPL"); return e ? atoi(e) : 0; }();   // debugging aid: overrides smt_asw_set_impl
+    const int impl = env_impl ? env_impl : g_asw_impl;
+    if (impl >= 3 && side >= 5) {
+        const int A3Q = impl == 4 ? 1 : 2;
         const int K = (D + 63) / 64, NXP = A3P * A3Q + 64 * K;
         const size_t shm3 = ((size_t)side * NXP + 256) * 8 + (size_t)(NXP + side) * 4;
         const size_t nt = (size_t)N * side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
@@ -849,29 +892,49 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         double *w0 = nullptr;
         unsigned *a32 = nullptr;
         if (shm3 <= 160 * 1024 && smt_scratch_alloc((void **)&w0, nt * 8, st) == hipSuccess) {
-            if (smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { (void)hipFreeAsync(w0, st); return SMT_ERR_ALLOC; }
+            if (smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { smt_scratch_free(w0, st); return SMT_ERR_ALLOC; }
+            int rc = SMT_OK;                              // one exit path: the scratch is freed whatever happens
             const uint8_t *Ap = v == 0 ? Lp : Rp;
+            static const bool verify = [] { const char *e = getenv("SMT_ASW_VERIFY"); return e && atoi(e) != 0; }();
+            unsigned long long *counts = nullptr;
+            auto check_tables = [&](const char *when) {
+                // diagnostic only: a synchronising read-back of the comparison of both tables with their definition
+                unsigned long long h[6] = {0, 0, 0, 0, ~0ull, 0};
+                if (hipMemcpyAsync(counts, h, sizeof h, hipMemcpyHostToDevice, st) != hipSuccess) return;
+                hipLaunchKernelGGL(k_asw_anchor_check, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32, counts);
+                if (hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+                fprintf(stderr, "SMT_ASW_VERIFY %s: w0=%p..+%zu a32=%p view=%d  w0_bad=%llu (zero=%llu nan=%llu first=%lld last=%lld of %zu) a32_bad=%llu\n",
+                        when, (void *)w0, nt * 8, (void *)a32, v, h[0], h[1], h[2], h[0] ? (long long)h[4] - 1 : -1ll,
+                        h[0] ? (long long)h[5] - 1 : -1ll, nt, h[3]);
+            };
+            if (verify && hipMalloc((void **)&counts, 64) != hipSuccess) counts = nullptr;
             hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32);
+            if (counts) check_tables("after k_asw_anchor");
             const dim3 grid((W + A3P * A3Q - 1) / (A3P * A3Q), H);
-#define SMT_ASW3(KK)                                                                                         \
+#define SMT_ASW3(KK, QQ, SL)                                                                                 \
     do {                                                                                                     \
-        if (A3Q == 2) {                                                                                      \
-            SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
-            hipLaunchKernelGGL((k_asw3<KK, 2>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
-        } else {                                                                                             \
-            SMT_HIP(hipFuncSetAttribute((const void *)k_asw3<KK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3)); \
-            hipLaunchKernelGGL((k_asw3<KK, 1>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
-        }                                                                                                    \
+        hipError_t e_ = hipFuncSetAttribute((const void *)k_asw3<KK, QQ, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3); \
+        if (e_ != hipSuccess) { g_smt_last_hip = (int)e_; rc = SMT_ERR_HIP; break; }                         \
+        hipLaunchKernelGGL((k_asw3<KK, QQ, SL>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+    } while (0)
+#define SMT_ASW3K(KK)                                                                                        \
+    do {                                                                                                     \
+        if (impl == 5) SMT_ASW3(KK, 2, false);                                                               \
+        else if (A3Q == 2) SMT_ASW3(KK, 2, true);                                                            \
+        else SMT_ASW3(KK, 1, true);                                                                          \
     } while (0)
             switch (K) {
-            case 1: SMT_ASW3(1); break;
-            case 2: SMT_ASW3(2); break;
-            case 3: SMT_ASW3(3); break;
-            default: SMT_ASW3(4); break;
+            case 1: SMT_ASW3K(1); break;
+            case 2: SMT_ASW3K(2); break;
+            case 3: SMT_ASW3K(3); break;
+            default: SMT_ASW3K(4); break;
             }
+#undef SMT_ASW3K
 #undef SMT_ASW3
-            (void)hipFreeAsync(w0, st);
-            (void)hipFreeAsync(a32, st);
+            if (counts) { check_tables("after k_asw3"); (void)hipFree(counts); }
+            smt_scratch_free(w0, st);
+            smt_scratch_free(a32, st);
+            if (rc != SMT_OK) return rc;
             SMT_LAUNCH_CHECK();
             return SMT_OK;
         }

@@ -70,3 +70,35 @@ def test_world_size_1_process_group_runs_production_callable(smt, O):
         assert abs(shard.checksum(gl) - float(gl.double().sum())) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_handle_on_second_device_while_first_is_current(smt, O):
+    """Needs two visible GPUs (skipped on the one-GPU boxes this suite normally runs on -- multi-device behaviour is
+    unverified there and DESIGN.md says so): handles created for cuda:1 while cuda:0 is current, tensors on cuda:1,
+    results against the oracle."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 1)
+    H, W, D = 40, 96, 64
+    L, R = O.synth_pair(H, W, D, 11)
+    Lf = torch.from_numpy(L.astype(np.float32)).to(dev)
+    Rf = torch.from_numpy(R.astype(np.float32)).to(dev)
+    adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+    dl, dr = torch.empty((H, W), device=dev), torch.empty((H, W), device=dev)
+    adc.ComputeBoth(dl, dr)
+    adc.status()
+    assert torch.cuda.current_device() == 0
+    ol = O.adcensus_view(L, R, D, 10.0, 30.0, 0)
+    assert np.array_equal(adc.GetPtrLeft().cpu().numpy().view(np.uint32), ol.view(np.uint32))
+    assert np.array_equal(dl.cpu().numpy(), O.wta(ol))
+    assert np.array_equal(smt.wta(adc.GetPtrLeft()).cpu().numpy(), O.wta(ol))      # stateless entry on the tensor's device
+    pipe = smt.Pipeline(H, W, D, dev)
+    pdl, pdr, cls, counts = pipe.run(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev))
+    cl, cr = ol, O.adcensus_view(L, R, D, 10.0, 30.0, 1)
+    ar, _ = O.aggregate_rect(cr, O.arms_all(R), 0)
+    assert np.array_equal(pdr[0].cpu().numpy(), O.wta(ar))
+    with pytest.raises(ValueError):
+        pipe.run(torch.from_numpy(L).to("cuda:0"), torch.from_numpy(R).to("cuda:0"))
+    pipe.close()
+    adc.close()
