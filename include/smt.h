@@ -234,6 +234,12 @@ int smt_crossarm_set_arm_walk(smt_crossarm *h, int on);
 /* Borrowed pointers to the int32 [H][W] arm maps (leftLength, rightLength, topLength,
  * buttonLenght; CrossArm.h:30-33). */
 int smt_crossarm_arm_maps(smt_crossarm *h, int **left, int **right, int **top, int **bottom);
+/* The other direction: arm maps the caller already has (DEVICE int32 [H][W] each) become the handle's maps, so that
+ * the aggregation entry below serves callers whose reference signature takes the four arrays --
+ * costAggregationV5(dispvolume, CostVolume, ArmvolumeL, ArmvolumeR, ArmvolumeUp, ArmvolumeDown, ...) (CBLSM.h:1179);
+ * CBLSM.cpp:150 aggregates the RIGHT view's volume with the LEFT image's arms this way.  Lengths outside 0..8191
+ * are clamped and make smt_crossarm_status return SMT_ERR_REF_UB. */
+int smt_crossarm_load_arm_maps(smt_crossarm *h, const int *left, const int *right, const int *top, const int *bottom);
 
 /* order 0: AggregationVertical (CrossArm.cpp:60-102), columns outer / rows inner;
  * order 1: costAggregationV5 (CBLSM.h:1179-1224), rows outer / columns inner;

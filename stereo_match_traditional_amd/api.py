@@ -303,6 +303,15 @@ class CrossArmAggregation:
         check(lib().smt_crossarm_arm_maps(self._h, *[C.byref(p) for p in ps]), "smt_crossarm_arm_maps")
         return [_view_of(p.value, (self.row, self.col), torch.int32, self.device) for p in ps]
 
+    def load_arm_maps(self, left, right, top, bottom):
+        """Arm maps computed elsewhere (int32 [row][col] device tensors) become this handle's maps -- the shape of
+        costAggregationV5(dispvolume, CostVolume, ArmvolumeL, ArmvolumeR, ArmvolumeUp, ArmvolumeDown, ...)."""
+        for t, nm in zip((left, right, top, bottom), ("left", "right", "top", "bottom")):
+            _dev(t, torch.int32, (self.row, self.col), nm)
+        self._bind()
+        check(lib().smt_crossarm_load_arm_maps(self._h, _ptr(left), _ptr(right), _ptr(top), _ptr(bottom)),
+              "smt_crossarm_load_arm_maps")
+
     def _agg(self, dispVolume, aggregatedCostVolume, order, disp):
         shp = (self.row, self.col, self.dispRange)
         _dev(dispVolume, torch.float32, shp, "dispVolume")

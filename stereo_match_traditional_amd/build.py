@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
 def build_host():
     """C++ host mirror (host/smt_host.hpp) + the main.cpp counterparts, plain g++ against the C ABI."""
     exes = []
-    for name in ("adcensus_main", "matchers_main"):
+    for name in ("adcensus_main", "matchers_main", "cblsm_main"):
         exe = os.path.join(HERE, "lib", name)
         cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", os.path.join(HERE, "host", name + ".cpp"),
                "-o", exe, "-L" + os.path.join(HERE, "lib"), "-lsmt_hip", "-Wl,-rpath,$ORIGIN"]

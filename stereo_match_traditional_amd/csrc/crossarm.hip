@@ -1392,6 +1392,36 @@ static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *di
 #undef SMT_AGG
 }
 
+// arm maps computed elsewhere (costAggregationV5 and AggregationVertical take them as plain int arrays):
+// copied into the handle; a length outside 0..8191 is not something either reference loop survives (its
+// rectangle leaves the plane or is empty: 0/0) -- clamped, and reported by smt_crossarm_status as SMT_ERR_REF_UB
+__global__ void __launch_bounds__(NT) k_load_arms(const int *__restrict__ l, const int *__restrict__ r, const int *__restrict__ t,
+                                                  const int *__restrict__ b, int *__restrict__ ol, int *__restrict__ orr,
+                                                  int *__restrict__ ot, int *__restrict__ ob, int n, int *ub_flag)
+{
+    const int p = blockIdx.x * NT + threadIdx.x;
+    if (p >= n) return;
+    const int v[4] = {l[p], r[p], t[p], b[p]};
+    bool bad = false;
+    int c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { c[k] = min(max(v[k], 0), 8191); bad = bad || c[k] != v[k]; }
+    ol[p] = c[0]; orr[p] = c[1]; ot[p] = c[2]; ob[p] = c[3];
+    if (bad) atomicOr(ub_flag, 1);
+}
+
+SMT_API int smt_crossarm_load_arm_maps(smt_crossarm *h, const int *left, const int *right, const int *top, const int *bottom)
+{
+    if (!h || !left || !right || !top || !bottom) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
+    const int n = h->H * h->W;
+    hipLaunchKernelGGL(k_load_arms, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, h->stream, left, right, top, bottom,
+                       h->arm[0], h->arm[1], h->arm[2], h->arm[3], n, h->flip + 4);
+    SMT_LAUNCH_CHECK();
+    h->have_arms = true;
+    return SMT_OK;
+}
+
 SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vout, int order, float *disp)
 {
     if (!h || !vin || !vout || vin == vout || order < 0 || order > 2) return SMT_ERR_ARG;

@@ -17,16 +17,19 @@ namespace {
 // ---- CRC-32 (PNG chunks) and Adler-32 (zlib trailer) ----------------------------------------------
 uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
 {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t k = 0; k < 256; k++) {
-            uint32_t c = k;
-            for (int b = 0; b < 8; b++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[k] = c;
+    struct Table {
+        uint32_t v[256];
+        Table()
+        {
+            for (uint32_t k = 0; k < 256; k++) {
+                uint32_t c = k;
+                for (int b = 0; b < 8; b++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                v[k] = c;
+            }
         }
-        init = true;
-    }
+    };
+    static const Table tab;                                // C++11: initialised once, thread-safe
+    const uint32_t *table = tab.v;
     crc = ~crc;
     for (size_t k = 0; k < n; k++) crc = table[(crc ^ p[k]) & 0xff] ^ (crc >> 8);
     return ~crc;
@@ -78,7 +81,7 @@ int decode_symbol(BitReader &br, const Huffman &h)
     }
     return -1;
 }
-bool inflate_codes(BitReader &br, std::vector<uint8_t> &out, const Huffman &lit, const Huffman &dist)
+bool inflate_codes(BitReader &br, std::vector<uint8_t> &out, const Huffman &lit, const Huffman &dist, size_t cap)
 {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -87,7 +90,7 @@ bool inflate_codes(BitReader &br, std::vector<uint8_t> &out, const Huffman &lit,
     for (;;) {
         int sym = decode_symbol(br, lit);
         if (sym < 0) return false;
-        if (sym < 256) out.push_back((uint8_t)sym);
+        if (sym < 256) { if (out.size() >= cap) return false; out.push_back((uint8_t)sym); }
         else if (sym == 256) return true;
         else {
             sym -= 257;
@@ -96,13 +99,16 @@ bool inflate_codes(BitReader &br, std::vector<uint8_t> &out, const Huffman &lit,
             const int ds = decode_symbol(br, dist);
             if (ds < 0 || ds >= 30) return false;
             const size_t d = (size_t)dbase[ds] + (size_t)br.bits(dext[ds]);
-            if (br.bad || d > out.size()) return false;
+            if (br.bad || d > out.size() || out.size() + (size_t)len > cap) return false;   // cap: no decompression bombs
             size_t from = out.size() - d;
             for (int k = 0; k < len; k++) out.push_back(out[from + k]);
         }
     }
 }
-bool zlib_inflate(const uint8_t *p, size_t n, std::vector<uint8_t> &out)
+// largest decoded image the reader accepts (65535 x 65535 is what the PNG checks above allow: 17 GB of RGBA16)
+constexpr size_t kMaxDecodedBytes = (size_t)1 << 31;
+
+bool zlib_inflate(const uint8_t *p, size_t n, std::vector<uint8_t> &out, size_t cap)
 {
     if (n < 6 || (p[0] & 0x0f) != 8 || ((p[0] << 8) | p[1]) % 31 != 0 || (p[1] & 0x20)) return false;
     BitReader br{p + 2, n - 2, 0, 0, 0, false};
@@ -116,7 +122,7 @@ bool zlib_inflate(const uint8_t *p, size_t n, std::vector<uint8_t> &out)
             if (br.pos + 4 > br.n) return false;
             const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
             br.pos += 4;
-            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n || out.size() + len > cap) return false;
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -156,7 +162,7 @@ bool zlib_inflate(const uint8_t *p, size_t n, std::vector<uint8_t> &out)
                 if (br.bad || lens[256] == 0) return false;
                 if (!build_huffman(lit, lens, nlen) || !build_huffman(dist, lens + nlen, ndist)) return false;
             }
-            if (!inflate_codes(br, out, lit, dist)) return false;
+            if (!inflate_codes(br, out, lit, dist, cap)) return false;
         } else return false;
     } while (!last);
     return !br.bad;
@@ -211,9 +217,13 @@ int decode_png(const std::vector<uint8_t> &f, std::vector<uint8_t> &pix, int &H,
     if (!depth_ok || (ctype == 3 && plte.size() < 3)) return SMT_ERR_ARG;
     const size_t bpp = (size_t)(spp * depth + 7) / 8;      // filter distance in bytes
     const size_t stride = ((size_t)w * spp * depth + 7) / 8;
+    // a deflate stream expands at most 1032:1, so a file of this size cannot hold more rows than that: refuse headers
+    // that promise more before reserving anything, and never inflate past the size the header implies
+    const size_t need = (stride + 1) * h;
+    if (need > kMaxDecodedBytes || need / 1032 > idat.size() + 1) return SMT_ERR_ARG;
     std::vector<uint8_t> raw;
-    raw.reserve((stride + 1) * h);
-    if (!zlib_inflate(idat.data(), idat.size(), raw) || raw.size() < (stride + 1) * h) return SMT_ERR_ARG;
+    raw.reserve(need);
+    if (!zlib_inflate(idat.data(), idat.size(), raw, need) || raw.size() < need) return SMT_ERR_ARG;
     // undo the scanline filters in place (row r at raw[r*(stride+1)+1])
     for (uint32_t r = 0; r < h; r++) {
         uint8_t *cur = &raw[(size_t)r * (stride + 1) + 1];
@@ -314,7 +324,7 @@ bool has_ext(const char *path, const char *ext)
 
 }  // namespace
 
-SMT_API int smt_image_read(const char *path, int want_channels, uint8_t **pixels, int *H, int *W, int *channels)
+static int image_read_impl(const char *path, int want_channels, uint8_t **pixels, int *H, int *W, int *channels)
 {
     if (!path || !pixels || !H || !W || !channels || (want_channels != 0 && want_channels != 1 && want_channels != 3))
         return SMT_ERR_ARG;
@@ -344,13 +354,25 @@ SMT_API int smt_image_read(const char *path, int want_channels, uint8_t **pixels
     return SMT_OK;
 }
 
+// The codec parses untrusted files behind a C ABI: no C++ exception may cross it.
+SMT_API int smt_image_read(const char *path, int want_channels, uint8_t **pixels, int *H, int *W, int *channels)
+{
+    try {
+        return image_read_impl(path, want_channels, pixels, H, W, channels);
+    } catch (const std::bad_alloc &) {
+        return SMT_ERR_ALLOC;
+    } catch (...) {
+        return SMT_ERR_ARG;
+    }
+}
+
 SMT_API int smt_image_free(uint8_t *pixels)
 {
     free(pixels);
     return SMT_OK;
 }
 
-SMT_API int smt_image_write(const char *path, const uint8_t *pixels, int H, int W, int channels)
+static int image_write_impl(const char *path, const uint8_t *pixels, int H, int W, int channels)
 {
     if (!path || !pixels || H <= 0 || W <= 0 || H > 65535 || W > 65535 || (channels != 1 && channels != 3)) return SMT_ERR_ARG;
     std::vector<uint8_t> out;
@@ -393,4 +415,15 @@ SMT_API int smt_image_write(const char *path, const uint8_t *pixels, int H, int 
     if (!fp) return SMT_ERR_ARG;
     const bool ok = fwrite(out.data(), 1, out.size(), fp) == out.size();
     return (fclose(fp) == 0 && ok) ? SMT_OK : SMT_ERR_ARG;
+}
+
+SMT_API int smt_image_write(const char *path, const uint8_t *pixels, int H, int W, int channels)
+{
+    try {
+        return image_write_impl(path, pixels, H, W, channels);
+    } catch (const std::bad_alloc &) {
+        return SMT_ERR_ALLOC;
+    } catch (...) {
+        return SMT_ERR_ARG;
+    }
 }

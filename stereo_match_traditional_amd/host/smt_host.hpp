@@ -470,6 +470,83 @@ inline Image cvtColorBGR2GRAY(const Image &bgr)
     return g;
 }
 
+// ------------------------------------------------------------------ CBLSM.h active path (CBLSM.cpp:64-67, 101-104, 133-153)
+// ArmLength{L,R,Up,Down}(const Mat&, uchar tao, int* arm, int maxLength, int secLength) (CBLSM.h:643, 536, 753, 861):
+// `tao` is BY VALUE -- every call starts from it again, the drop to 6 past secLength is local to the call.
+inline void arm_length_(const Image &image, unsigned char tao, int *arm, int maxLength, int secLength, int dir)
+{
+    smt_crossarm_params p;
+    smt_crossarm_cblsm_params(&p);
+    p.tau = tao; p.max_length = maxLength; p.sec_length = secLength;
+    smt_crossarm *h = nullptr;
+    check(smt_crossarm_create(image.rows, image.cols, 1, &p, &h), "smt_crossarm_create");
+    try {
+        DevBuf<unsigned char> img(image.data.size());
+        img.upload(image.data.data());
+        check(smt_crossarm_reset(h), "smt_crossarm_reset");
+        check(smt_crossarm_arm_dir(h, img.get(), image.channels, dir), "smt_crossarm_arm_dir");
+        int *maps[4] = {nullptr, nullptr, nullptr, nullptr};
+        check(smt_crossarm_arm_maps(h, &maps[0], &maps[1], &maps[2], &maps[3]), "smt_crossarm_arm_maps");
+        check(smt_memcpy_d2h(arm, maps[dir], (size_t)image.rows * image.cols * sizeof(int), nullptr), "d2h");
+        check(smt_stream_sync(nullptr), "sync");
+    } catch (...) { smt_crossarm_destroy(h); throw; }
+    smt_crossarm_destroy(h);
+}
+inline void ArmLengthL(const Image &image, unsigned char tao, int *LArm, int maxLength, int secLength) { arm_length_(image, tao, LArm, maxLength, secLength, 0); }
+inline void ArmLengthR(const Image &image, unsigned char tao, int *RArm, int maxLength, int secLength) { arm_length_(image, tao, RArm, maxLength, secLength, 1); }
+inline void ArmLengthUp(const Image &image, unsigned char tao, int *UpArm, int maxLength, int secLength) { arm_length_(image, tao, UpArm, maxLength, secLength, 2); }
+inline void ArmLengthDown(const Image &image, unsigned char tao, int *DownArm, int maxLength, int secLength) { arm_length_(image, tao, DownArm, maxLength, secLength, 3); }
+
+// ComputeAD / ComputeADRight (CBLSM.h:327-381): uchar absolute differences into a float [row][col][dispRange] volume
+inline void compute_ad_(int col, int row, int dispRange, const unsigned char *leftImage, const unsigned char *rightImage,
+                        float *ADcostVolum, int view)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<unsigned char> L(n), R(n);
+    DevBuf<float> vol(n * dispRange);
+    L.upload(leftImage); R.upload(rightImage);
+    check(smt_cblsm_ad(L.get(), R.get(), row, col, dispRange, view, vol.get(), nullptr), "smt_cblsm_ad");
+    vol.download(ADcostVolum);
+}
+inline void ComputeAD(int col, int row, int dispRange, unsigned char *leftImage, unsigned char *rightImage, float *ADcostVolum)
+{ compute_ad_(col, row, dispRange, leftImage, rightImage, ADcostVolum, SMT_VIEW_LEFT); }
+inline void ComputeADRight(int col, int row, int dispRange, unsigned char *leftImage, unsigned char *rightImage, float *ADcostVolum)
+{ compute_ad_(col, row, dispRange, leftImage, rightImage, ADcostVolum, SMT_VIEW_RIGHT); }
+
+// costAggregationV5 (CBLSM.h:1179-1224): rectangle mean, rows outer / columns inner, with the four arm arrays the
+// caller passes -- whichever image they were computed on (CBLSM.cpp:150 aggregates the right volume with the left
+// image's arms).  winSize is unused by the reference too.
+inline void costAggregationV5(float *dispvolume, float *CostVolume, int *ArmvolumeL, int *ArmvolumeR, int *ArmvolumeUp,
+                              int *ArmvolumeDown, int dispRange, int row, int col, int /*winSize*/)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<float> in(n * dispRange), out(n * dispRange);
+    DevBuf<int> aL(n), aR(n), aU(n), aD(n);
+    in.upload(dispvolume);
+    aL.upload(ArmvolumeL); aR.upload(ArmvolumeR); aU.upload(ArmvolumeUp); aD.upload(ArmvolumeDown);
+    smt_crossarm_params p;
+    smt_crossarm_cblsm_params(&p);
+    smt_crossarm *h = nullptr;
+    check(smt_crossarm_create(row, col, dispRange, &p, &h), "smt_crossarm_create");
+    try {
+        check(smt_crossarm_load_arm_maps(h, aL.get(), aR.get(), aU.get(), aD.get()), "smt_crossarm_load_arm_maps");
+        check(smt_crossarm_aggregate(h, in.get(), out.get(), 1, nullptr), "smt_crossarm_aggregate");
+        out.download(CostVolume);
+        check(smt_crossarm_status(h), "smt_crossarm_status");
+    } catch (...) { smt_crossarm_destroy(h); throw; }
+    smt_crossarm_destroy(h);
+}
+
+// ComputeDispOringin (CBLSM.h:383-407): first strict minimum over d
+inline void ComputeDispOringin(float *costVolume, float *disp, int dispRange, int row, int col)
+{
+    const size_t n = (size_t)row * col;
+    DevBuf<float> v(n * dispRange), d(n);
+    v.upload(costVolume);
+    check(smt_wta(v.get(), row, col, dispRange, d.get(), nullptr), "smt_wta");
+    d.download(disp);
+}
+
 // ------------------------------------------------------------------ config 5: a batch over the node's GPUs
 // One host thread, one smt_adcensus handle per device (smt_adcensus_create_on); pair b goes to device
 // b % G as a contiguous block per device; no data-path exchange between devices (pairs are independent,

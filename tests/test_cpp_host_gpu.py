@@ -117,3 +117,83 @@ def test_batch_with_rccl_exchange(smt, O):
         Lg, Rg = O.synth_pair(H, W, D, 1000 + b)
         assert l[3] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 0))):016x}", b
         assert l[5] == f"{O.fnv1a(O.wta(O.adcensus_view(Lg, Rg, D, 10.0, 30.0, 1))):016x}", b
+
+
+def _cblsm_oracle(O, L, R, D):
+    """CBLSM.cpp:64-67, 101-104, 133-153 composed from the oracle's pieces, in the file's order."""
+    aL = O.arms_all(L, tau0=25, tau_low=6, sec=17, maxlen=34, chain=False, right_row_bug=False)
+    aR = O.arms_all(R, tau0=25, tau_low=6, sec=17, maxlen=34, chain=False, right_row_bug=False)
+    adl, adr = O.cblsm_ad(L, R, D, 0), O.cblsm_ad(L, R, D, 1)                   # :133-134
+    cr, _ = O.aggregate_rect(adr, aR, 1)                                       # :146 right volume, right arms
+    cl, _ = O.aggregate_rect(adl, aL, 1)                                       # :147
+    cl2, _ = O.aggregate_rect(cl, aL, 1)                                       # :149
+    cr2, _ = O.aggregate_rect(cr, aL, 1)                                       # :150 right volume, LEFT arms
+    return aL, aR, adl, adr, cl, cr, cl2, cr2, O.wta(cl2), O.wta(cr2)           # :152-153
+
+
+def test_cblsm_main_counterpart(smt, O):
+    """host/cblsm_main.cpp = CBLSM.cpp's active sequence through the C++ mirror (smt_host.hpp: ArmLength*, ComputeAD*,
+    costAggregationV5 with caller-held arm arrays, ComputeDispOringin) at CBLSM.cpp's own size class, 450x375 D=60
+    (:28-32): every product against the oracle composition -- the second right-view pass on the LEFT arms included."""
+    exe = os.path.join(ROOT, "stereo_match_traditional_amd", "lib", "cblsm_main")
+    assert os.path.exists(exe)
+    H, W, D, seed = 375, 450, 60, 6
+    r = subprocess.run([exe, str(H), str(W), str(D), str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = dict(line.split() for line in r.stdout.strip().splitlines())
+    L, R = O.synth_pair(H, W, D, seed)
+    aL, aR, adl, adr, cl, cr, cl2, cr2, dl, dr = _cblsm_oracle(O, L, R, D)
+    exp = {"arm_LL": aL[0], "arm_LR": aL[1], "arm_Lup": aL[2], "arm_Ldown": aL[3],
+           "arm_RL": aR[0], "arm_RR": aR[1], "arm_Rup": aR[2], "arm_Rdown": aR[3],
+           "ad_left": adl, "ad_right": adr, "agg_left": cl, "agg_right": cr, "agg_left_sec": cl2, "agg_right_sec": cr2,
+           "disp_left": dl, "disp_right": dr}
+    for k, v in exp.items():
+        assert got[k] == f"{O.fnv1a(v):016x}", k
+    # the quirk is visible: aggregating the right volume with its own arms gives a different volume
+    cr2_own, _ = O.aggregate_rect(cr, aR, 1)
+    assert not np.array_equal(cr2_own, cr2)
+
+
+def test_cblsm_flow_python_api(smt, O):
+    """The same sequence through the Python mirror on device tensors, one crossarm handle per image, the right
+    volume's second pass on the LEFT handle (CBLSM.cpp:150); maps and volumes bit-equal to the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    H, W, D, seed = 120, 200, 60, 8
+    L, R = O.synth_pair(H, W, D, seed)
+    aL, aR, adl, adr, cl, cr, cl2, cr2, dl, dr = _cblsm_oracle(O, L, R, D)
+    Lt, Rt = T(L), T(R)
+    caL = smt.CrossArmAggregation().Initialize(H, W, 25, D, dev, style="cblsm")
+    caR = smt.CrossArmAggregation().Initialize(H, W, 25, D, dev, style="cblsm")
+    for ca, img, ref in ((caL, Lt, aL), (caR, Rt, aR)):
+        ca.Reset()
+        ca.ComputeLeftArmLength(img); ca.ComputeRightArmLength(img); ca.ComputeTopArmLength(img); ca.ComputeButtonArmLength(img)
+        for m, a in zip(ca.arm_maps(), ref):
+            assert np.array_equal(m.cpu().numpy(), a)
+    vl, vr = smt.cblsm_ComputeAD(Lt, Rt, D, smt.VIEW_LEFT), smt.cblsm_ComputeAD(Lt, Rt, D, smt.VIEW_RIGHT)
+    gr, gl, gl2, gr2 = (torch.empty_like(vl) for _ in range(4))
+    dL, dR = torch.empty((H, W), device=dev), torch.empty((H, W), device=dev)
+    caR.costAggregationV5(vr, gr)
+    caL.costAggregationV5(vl, gl)
+    caL.costAggregationV5(gl, gl2, dL)
+    caL.costAggregationV5(gr, gr2, dR)                                         # left arms on the right volume
+    caL.status(); caR.status()
+    bits = lambda a: a.cpu().numpy().view(np.uint32)
+    for got, ref in ((gl, cl), (gr, cr), (gl2, cl2), (gr2, cr2)):
+        assert np.array_equal(bits(got), ref.view(np.uint32))
+    assert np.array_equal(dL.cpu().numpy(), dl) and np.array_equal(dR.cpu().numpy(), dr)
+    # caller-held arm arrays (costAggregationV5's own signature): the right image's maps loaded into a third handle
+    ca3 = smt.CrossArmAggregation().Initialize(H, W, 25, D, dev, style="cblsm")
+    ca3.load_arm_maps(*[T(a) for a in aR])
+    g3 = torch.empty_like(vr)
+    ca3.costAggregationV5(vr, g3)
+    ca3.status()
+    assert np.array_equal(bits(g3), cr.view(np.uint32))
+    bad = [a.copy() for a in aR]
+    bad[0][3, 4] = -1
+    ca3.load_arm_maps(*[T(a) for a in bad])
+    with pytest.raises(smt.SmtError):
+        ca3.status()
+    for c in (caL, caR, ca3):
+        c.close()

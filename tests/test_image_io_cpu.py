@@ -136,3 +136,30 @@ def test_bad_files_are_rejected(smt, tmp_path):
         smt.imread(tmp_path / "missing.png")
     with pytest.raises(SmtError):
         smt.imwrite(tmp_path / "x.jpg", np.zeros((2, 2), np.uint8))
+
+
+def test_hostile_png_headers_are_refused_not_fatal(smt, tmp_path):
+    """The reader parses untrusted files behind a C ABI: a header that promises gigabytes over a tiny stream, and a
+    stream that inflates past what its header implies (a decompression bomb), must come back as an error code --
+    no std::bad_alloc / length_error through ctypes, no unbounded growth."""
+    from stereo_match_traditional_amd import SmtError
+    sig = b"\x89PNG\r\n\x1a\n"
+    # 60000 x 60000 RGBA16 (28.8 GB decoded) over a 20-byte IDAT
+    p1 = tmp_path / "huge.png"
+    p1.write_bytes(sig + _chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 16, 6, 0, 0, 0)) +
+                   _chunk(b"IDAT", zlib.compress(b"\x00" * 64)) + _chunk(b"IEND", b""))
+    with pytest.raises(SmtError):
+        smt.imread(str(p1))
+    # 4 x 4 gray header, 64 MB of zeros in the stream
+    p2 = tmp_path / "bomb.png"
+    p2.write_bytes(sig + _chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 0)) +
+                   _chunk(b"IDAT", zlib.compress(b"\x00" * (64 << 20), 9)) + _chunk(b"IEND", b""))
+    with pytest.raises(SmtError):
+        smt.imread(str(p2))
+    # and a well-formed file still reads after the refusals
+    img = (np.arange(12, dtype=np.uint8).reshape(3, 4) * 20)
+    p3 = tmp_path / "ok.png"
+    p3.write_bytes(make_png([bytes(r) for r in img], 4, 3, 0, 8, 1, [0, 1, 2]))
+    got = smt.imread(str(p3), 1)
+    got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+    assert np.array_equal(got.reshape(3, 4), img)
