@@ -122,6 +122,17 @@ int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms
  * (ADcostVolum, CensusVolum, ...) are never materialised. */
 int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out);
 int smt_adcensus_create_on(int device, int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out);
+/* The same with the two measuring steps of Initialize under the caller's control (device < 0: the current one).
+ * Without flags smt_adcensus_create allocates up to six candidate pairs of volumes (transiently 6 x 2 x 4*H*W*D
+ * bytes: 19 GB at 1920x1080x192) to pick the placement with the fastest stores, and times the cost kernel with
+ * streaming and with ordinary stores -- tens of milliseconds, worth it for a handle that lives for a batch, wrong
+ * for a caller that creates a handle per request or shares the device:
+ *   SMT_ADCENSUS_NO_PLACEMENT_SEARCH   keep the first allocation of the volumes
+ *   SMT_ADCENSUS_NO_STORE_CALIBRATION  streaming stores without timing the alternative
+ * (SMT_PLACEMENT=0 / SMT_STORE_MODE in the environment still do the same process-wide.) */
+#define SMT_ADCENSUS_NO_PLACEMENT_SEARCH 0x1u
+#define SMT_ADCENSUS_NO_STORE_CALIBRATION 0x2u
+int smt_adcensus_create_ex(int device, int H, int W, int D, float sigmaC, float sigmaS, unsigned flags, smt_adcensus **out);
 int smt_adcensus_destroy(smt_adcensus *h);
 /* How smt_adcensus_create placed the two volumes: it allocates up to 6 candidate pairs, times a
  * store-only twin of the cost kernel on each and keeps the fastest (the HBM write rate of the same

@@ -90,7 +90,9 @@ class AD_Census:
     def __init__(self):
         self._h = None
 
-    def Initialize(self, leftImage, rightImage, dispRange, row, col, sigmaC, sigmaS):
+    def Initialize(self, leftImage, rightImage, dispRange, row, col, sigmaC, sigmaS, placement_search=True, store_calibration=True):
+        """AD-Census.h:322-344.  placement_search / store_calibration = False skip the two measuring steps of
+        smt_adcensus_create (smt_adcensus_create_ex flags): for handles created per request."""
         self.row, self.col, self.dispRange = int(row), int(col), int(dispRange)
         self._L = _dev(leftImage, torch.float32, (row, col), "leftImage")
         self._R = _dev(rightImage, torch.float32, (row, col), "rightImage")
@@ -98,8 +100,9 @@ class AD_Census:
         h = C.c_void_p()
         if rightImage.device != self.device:
             raise ValueError("leftImage and rightImage live on different devices")
-        check(lib().smt_adcensus_create_on(_dev_index(self.device), self.row, self.col, self.dispRange, C.c_float(sigmaC),
-                                           C.c_float(sigmaS), C.byref(h)), "smt_adcensus_create_on")
+        flags = (0 if placement_search else 1) | (0 if store_calibration else 2)
+        check(lib().smt_adcensus_create_ex(_dev_index(self.device), self.row, self.col, self.dispRange, C.c_float(sigmaC),
+                                           C.c_float(sigmaS), C.c_uint(flags), C.byref(h)), "smt_adcensus_create_ex")
         self._h = h
         self._views = 0
         return self

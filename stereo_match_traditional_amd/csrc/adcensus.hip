@@ -757,12 +757,12 @@ static void store_only(smt_adcensus *h, float *v0, float *v1, hipStream_t st)
 // ~5 ms per candidate at 1080p x 192), keeps the fastest and frees the rest.  Rejected candidates stay
 // allocated until the end so that every try gets different pages.  SMT_PLACEMENT=0 in the environment
 // turns the search off (first allocation is used).
-static int place_volumes(smt_adcensus *h)
+static int place_volumes(smt_adcensus *h, bool allow_search)
 {
     const size_t V = (size_t)h->H * h->W * h->D;
     constexpr int PLACE_TRIES = 6;
     const char *env = getenv("SMT_PLACEMENT");
-    const bool search = !(env && env[0] == '0') && h->D % 64 == 0 && h->D <= 256 && V >= ((size_t)1 << 22);
+    const bool search = allow_search && !(env && env[0] == '0') && h->D % 64 == 0 && h->D <= 256 && V >= ((size_t)1 << 22);
     float *cand[PLACE_TRIES][2] = {};
     float ms[PLACE_TRIES];
     int n = 0, best = -1;
@@ -804,12 +804,13 @@ static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR);
 // section 4).  Like the placement this is a property of the device, so Initialize times the real both-views
 // kernel a few launches each way on the handle's own (zeroed) tables and volumes and keeps ordinary stores
 // only when they win by more than 2 %.  SMT_STORE_MODE=nt / plain in the environment fixes the choice.
-static void calibrate_store_mode(smt_adcensus *h)
+static void calibrate_store_mode(smt_adcensus *h, bool allow)
 {
     h->plain_stores = false; h->store_mode_ms[0] = h->store_mode_ms[1] = 0.0f;
     const char *env = getenv("SMT_STORE_MODE");
     if (env && env[0] == 'p') { h->plain_stores = true; return; }
     if (env && env[0] == 'n') return;
+    if (!allow) return;
     const size_t V = (size_t)h->H * h->W * h->D;
     if (h->D % 64 != 0 || V < ((size_t)1 << 22)) return;
     const size_t N = (size_t)h->H * h->W;
@@ -873,7 +874,7 @@ SMT_API int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_onl
     return SMT_OK;
 }
 
-SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
+static int adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, unsigned flags, smt_adcensus **out)
 {
     if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256 || !(sigmaC > 0.0f) || !(sigmaS > 0.0f))
         return SMT_ERR_ARG;
@@ -885,7 +886,7 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
     h->n_pairs = 0;
     const size_t N = (size_t)H * W, V = N * D;
     const int WX = W + 4;
-    int rc = place_volumes(h);
+    int rc = place_volumes(h, !(flags & SMT_ADCENSUS_NO_PLACEMENT_SEARCH));
     auto alloc = [&](void **p, size_t bytes) { if (rc == SMT_OK) rc = smt_malloc(p, bytes); };
     alloc((void **)&h->TS[0].lut, 320 * 4);
     alloc((void **)&h->TS[0].flag, 4);
@@ -926,9 +927,24 @@ SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS,
         smt_adcensus_destroy(h);
         return SMT_ERR_HIP;
     }
-    calibrate_store_mode(h);
+    calibrate_store_mode(h, !(flags & SMT_ADCENSUS_NO_STORE_CALIBRATION));
     *out = h;
     return SMT_OK;
+}
+
+SMT_API int smt_adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
+{
+    return adcensus_create(H, W, D, sigmaC, sigmaS, 0u, out);
+}
+
+SMT_API int smt_adcensus_create_ex(int device, int H, int W, int D, float sigmaC, float sigmaS, unsigned flags, smt_adcensus **out)
+{
+    if (flags & ~(unsigned)(SMT_ADCENSUS_NO_PLACEMENT_SEARCH | SMT_ADCENSUS_NO_STORE_CALIBRATION)) return SMT_ERR_ARG;
+    if (device < 0) return adcensus_create(H, W, D, sigmaC, sigmaS, flags, out);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device >= n) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(device);
+    return adcensus_create(H, W, D, sigmaC, sigmaS, flags, out);
 }
 
 SMT_API int smt_adcensus_create_on(int device, int H, int W, int D, float sigmaC, float sigmaS, smt_adcensus **out)
@@ -1177,20 +1193,34 @@ SMT_API int smt_adcensus_kernel_times(smt_adcensus *h, float *prep_ms, float *co
 }
 
 // Measurement hook (bench.py): see include/smt.h.
-SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms,
-                              float *store_only_ms)
+namespace {
+// everything smt_adcensus_diag_impl acquires, released on every exit path (its SMT_HIP early returns included)
+struct DiagResources {
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    unsigned long long *stamp = nullptr;
+    unsigned long long *hs = nullptr;
+    float *ratio = nullptr;
+    ~DiagResources()
+    {
+        for (auto &x : e) if (x) (void)hipEventDestroy(x);
+        if (stamp) (void)hipFree(stamp);
+        delete[] hs;
+        delete[] ratio;
+    }
+};
+}  // namespace
+
+static int smt_adcensus_diag_impl(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms, float *store_only_ms, DiagResources &res)
 {
-    if (!h || reps <= 0 || reps > 1000) return SMT_ERR_ARG;
-    smt_dev_guard dev_guard(h->device);
     if (h->n_pairs == 0) return SMT_ERR_STATE;               // needs the tables of a computed pair
     const int D = h->D, C = D / 64;
     if (D % 64 != 0 || C < 1 || C > 4) return SMT_ERR_ARG;
     const int nbx = (h->W + FTJ - 1) / FTJ;
     const unsigned nblk = (unsigned)(((long)nbx * h->H * 2 + 7) / 8 * 8);
-    hipEvent_t e[3];
+    hipEvent_t (&e)[3] = res.e;
     for (auto &x : e) SMT_HIP(hipEventCreate(&x));
-    unsigned long long *stamp = nullptr;
-    if (smt_malloc((void **)&stamp, (size_t)nblk * 32) != SMT_OK) return SMT_ERR_ALLOC;
+    if (smt_malloc((void **)&res.stamp, (size_t)nblk * 32) != SMT_OK) return SMT_ERR_ALLOC;
+    unsigned long long *stamp = res.stamp;
     SMT_HIP(hipMemsetAsync(stamp, 0, (size_t)nblk * 32, h->stream));
     Tables T = h->T;
     T.stamp = stamp;
@@ -1231,9 +1261,9 @@ SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float 
     if (cost_ms) *cost_ms = b / reps;
     if (sclk_mhz) {
         // stamps of the last launch: median over workgroups of d(s_memtime) / d(s_memrealtime) * 100 MHz
-        unsigned long long *hs = new (std::nothrow) unsigned long long[(size_t)nblk * 4];
-        float *ratio = new (std::nothrow) float[nblk];
-        if (!hs || !ratio) { delete[] hs; delete[] ratio; (void)hipFree(stamp); return SMT_ERR_ALLOC; }
+        unsigned long long *hs = res.hs = new (std::nothrow) unsigned long long[(size_t)nblk * 4];
+        float *ratio = res.ratio = new (std::nothrow) float[nblk];
+        if (!hs || !ratio) return SMT_ERR_ALLOC;
         SMT_HIP(hipMemcpy(hs, stamp, (size_t)nblk * 32, hipMemcpyDeviceToHost));
         size_t n = 0;
         for (unsigned k = 0; k < nblk; k++) {
@@ -1242,11 +1272,16 @@ SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float 
         }
         if (n) { std::nth_element(ratio, ratio + n / 2, ratio + n); *sclk_mhz = ratio[n / 2]; }
         else *sclk_mhz = 0.0f;
-        delete[] hs; delete[] ratio;
     }
-    for (auto &x : e) (void)hipEventDestroy(x);
-    SMT_HIP(hipFree(stamp));
     return SMT_OK;
+}
+
+SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float *cost_ms, float *store_only_ms)
+{
+    if (!h || reps <= 0 || reps > 1000) return SMT_ERR_ARG;
+    smt_dev_guard dev_guard(h->device);
+    DiagResources res;
+    return smt_adcensus_diag_impl(h, reps, sclk_mhz, cost_ms, store_only_ms, res);
 }
 
 SMT_API int smt_wta(const float *vol, int H, int W, int D, float *disp, void *stream)

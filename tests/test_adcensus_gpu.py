@@ -304,3 +304,29 @@ def test_calibrated_handle_still_starts_zeroed(smt):
     assert int(adc.GetPtrRight().view(torch.int32).abs().max()) == 0
     adc.status()
     adc.close()
+
+
+def test_create_ex_flags_skip_the_measuring_steps(smt, O):
+    """smt_adcensus_create_ex: without flags Initialize times up to six placements and both store modes on a
+    volume this large; with both flags it keeps the first allocation and streaming stores -- and computes the same bits."""
+    import torch
+    dev = torch.device("cuda:0")
+    H, W, D = 96, 704, 64                                   # H*W*D = 2^22 hypotheses: the smallest size the search runs at
+    L, R = O.synth_pair(H, W, D, 13)
+    Lf = torch.from_numpy(L.astype(np.float32)).to(dev)
+    Rf = torch.from_numpy(R.astype(np.float32)).to(dev)
+    vols = []
+    for kw in ({}, {"placement_search": False, "store_calibration": False}):
+        adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0, **kw)
+        tries, ms = adc.placement()
+        plain, nt_ms, plain_ms = adc.store_mode()
+        if kw:
+            assert (tries, ms) == (1, 0.0) and not plain and nt_ms == 0.0 and plain_ms == 0.0
+        else:
+            assert tries >= 1 and ms > 0.0 and nt_ms > 0.0 and plain_ms > 0.0
+        adc.ComputeADcensus()
+        adc.status()
+        vols.append(adc.GetPtrLeft().cpu().numpy().copy())
+        adc.close()
+    assert np.array_equal(vols[0].view(np.uint32), vols[1].view(np.uint32))
+    assert np.array_equal(vols[0].view(np.uint32), O.adcensus_view(L, R, D, 10.0, 30.0, 0).view(np.uint32))
