@@ -277,6 +277,11 @@ int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps (all variants but 1;
  * variants 3 and 4 round it to 8, 16 or a multiple of 32). */
 int smt_crossarm_set_strip_width(smt_crossarm *h, int width);
+/* Tuning hook: aggregation waves per SIMD (3, 4 or 5, enforced through an LDS claim per workgroup; 0 = whatever the
+ * register count allows, i.e. 6).  Default 4: the aggregation is no slower than at 6, and 192 of a SIMD's 512
+ * VGPRs stay free for kernels of other streams (the scanline passes of smt_pipeline_run_batch run beside it).
+ * SMT_AGG_WAVES in the environment overrides the default for every handle. */
+int smt_crossarm_set_occupancy(smt_crossarm *h, int waves_per_simd);
 /* Tuning hook (variants 3-5): 0 = column strips interleaved over the 8 XCDs, 1 = every XCD owns one
  * contiguous band of rows and sweeps it strip by strip.  Placement only; results are identical. */
 int smt_crossarm_set_sweep(smt_crossarm *h, int sweep);

@@ -23,6 +23,7 @@
 // spans the disparity axis of a pixel (lane l owns C consecutive d), so every tap is one
 // coalesced 64*C*4-byte read that neighbouring pixels' waves re-read from L2.
 #include "smt_common.h"
+#include <stdlib.h>
 #include <limits.h>
 #include <new>
 #include <type_traits>
@@ -639,7 +640,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
 template <int C, int ORDER, bool FULL, int QR, int SKIP>
-__global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
@@ -653,7 +654,24 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
     // tiles whose unions overlap; an XCD's 4 MB L2 is refilled every ~5 us at this kernel's fetch rate, so a
     // line fetched for one tile is gone before a free-running neighbour asks for it (TCC: ~10 fabric fetches
     // per input line).  Walking the same columns at the same time turns those re-fetches into L2 hits.
-    constexpr bool SYNC = (SKIP == 3);
+    // SKIP == 4 / 5 ("matrix"): the lock-step kernel with the flagged accumulate on the matrix pipe.  For a group of
+    // four pixels v_mfma_f32_4x4x1_16b_f32 computes, in every 4-lane block, D[i][j] = A[i] * B[j] + C[i][j]: with A =
+    // the four membership flags (lane l carries the flag of pixel l % 4 of the group) and B = the tap's row (lane l
+    // carries its hypotheses as before), accumulator register i of lane l becomes acc_i[l] + flag_i * x[l] -- the same
+    // one-rounding fma per element as v_pk_fma_f32 (tools/mfma_flag_probe.hip: bit-identical to the v_fma chain and
+    // to plain adds on 4 096 taps of normal, denormal, negative and huge values), in the accumulator layout the
+    // kernel already has, at the same 256 FMA per 8 cycles per SIMD -- but on the other pipe, in 12 instructions per
+    // tap instead of 2.4 x (6 v_pk_fma + v_mov), with no flag rows to fetch through the scalar cache (the flags are
+    // two VALU operations on the membership mask) and, for SKIP == 4, no branch in the tap loop at all.
+    // 5 = the same with the group-skip branches kept.  6 = 4 with ONE A register per tap: lane l < 16 carries the flag
+    // of pixel l, and the instruction's A-broadcast field (CBSZ = 4: all 16 blocks read the A values of block ABID)
+    // picks group g's four lanes -- two VALU operations per tap instead of two per group.
+    constexpr bool MFMA = (SKIP >= 4);
+    static_assert(SKIP <= 7, "");
+    constexpr bool MSKIP = (SKIP == 5);
+    constexpr bool MBCAST = (SKIP == 6);
+    constexpr bool MHACK = (SKIP == 7);                  // TIMING EXPERIMENT ONLY (results wrong): 3 x 16x16x4 per tap
+    constexpr bool SYNC = (SKIP >= 3);
     constexpr bool PREF = (SKIP >= 2);                   // flag rows fetched one tap ahead + per-axis tables
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -727,17 +745,74 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
     unsigned pk_i = (unsigned)(my_ia + BIAS) | ((unsigned)(my_ib + BIAS) << 16);
 
     const int dl = lane * C;
-    f2 acc[NPIX / 2][C];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f2 acc[MFMA ? 1 : NPIX / 2][C];
+    f4 macc[MFMA ? NPIX / 4 : 1][C];                       // matrix formulation: group g = pixels 4g .. 4g + 3, register i = pixel 4g + i
 #pragma unroll
-    for (int j = 0; j < NPIX / 2; j++)
+    for (int j = 0; j < (MFMA ? 1 : NPIX / 2); j++)
 #pragma unroll
         for (int k = 0; k < C; k++) acc[j][k] = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < (MFMA ? NPIX / 4 : 1); j++)
+#pragma unroll
+        for (int k = 0; k < C; k++) macc[j][k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    // bit of the membership mask that lane l turns into its A operand for group g: 4g + (l & 3)
+    int mshift[MFMA ? NPIX / 4 : 1];
+#pragma unroll
+    for (int g = 0; g < (MFMA ? NPIX / 4 : 1); g++) mshift[g] = 4 * g + (lane & 3);
+    const int mshift16 = lane & 15;
+    int hack_rot = 0;
+    auto mfma_flagged = [&](unsigned m, const float (&x)[C]) {
+        if (MHACK) {
+            // same matrix-pipe time per tap as twelve 4x4x1 (3 x 32 cycles), a quarter of the instructions; 12 live accumulators
+            const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int g = (hack_rot + c) & 3;
+                if (g == 0) macc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[0][c], 0, 0, 0);
+                else if (g == 1) macc[NPIX > 4 ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 4 ? 1 : 0][c], 0, 0, 0);
+                else if (g == 2) macc[NPIX > 8 ? 2 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 8 ? 2 : 0][c], 0, 0, 0);
+                else macc[NPIX > 8 ? 3 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 8 ? 3 : 0][c], 0, 0, 0);
+            }
+            hack_rot++;
+            return;
+        }
+        if (MBCAST) {
+            const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                macc[0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[0][c], 4, 0, 0);
+                if (NPIX > 4) macc[MFMA && NPIX > 4 ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 4 ? 1 : 0][c], 4, 1, 0);
+                if (NPIX > 8) macc[MFMA && NPIX > 8 ? 2 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 8 ? 2 : 0][c], 4, 2, 0);
+                if (NPIX > 8) macc[MFMA && NPIX > 8 ? 3 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 8 ? 3 : 0][c], 4, 3, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int g = 0; g < NPIX / 4; g++) {
+            auto body = [&]() {
+                // 0.0f or 1.0f: sign-extended 1-bit field (0 / -1) ANDed with the bits of 1.0f
+                const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift[MFMA ? g : 0], 1) & 0x3f800000);
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    macc[MFMA ? g : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA ? g : 0][c], 0, 0, 0);
+            };
+            if (!MSKIP) body();
+            else if ((m >> (4 * g)) & 15u) body();
+        }
+    };
     const unsigned lane_off = (unsigned)dl * 4u;
     // taps are fetched as buffer loads: wave-uniform byte offset of the tap in an SGPR, the lane's
     // disparity offset in a VGPR, no per-tap address arithmetic (volume < 4 GiB, checked by the host)
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)vin, 0, (int)((unsigned)N * (unsigned)(D * 4)), 0x00020000);
     auto ld = [&](unsigned off, float (&x)[C]) {
+#if defined(SMT_AGG_KNOCKOUT) && SMT_AGG_KNOCKOUT == 2
+        // diagnostic build: no tap is loaded (values made from the offset): the issue side of the kernel alone
+#pragma unroll
+        for (int k = 0; k < C; k++) x[k] = __int_as_float((int)(off >> 8) + k + (int)lane_off);
+        return;
+#endif
         if (FULL) {
             if (C == 1) x[0] = __int_as_float(buf_ld1(rsrc, lane_off, off));
             else if (C == 2) {
@@ -770,7 +845,7 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
                 const f2 fl = f2{f[2 * j], f[2 * j + 1]};
 #pragma unroll
                 for (int c = 0; c < C; c++)
-                    acc[4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+                    acc[MFMA ? 0 : 4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[MFMA ? 0 : 4 * h + j][c]);
             };
             if (SKIP == 0) {
 #pragma unroll
@@ -792,6 +867,14 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
         for (int h = 0; h < QR; h++) F[h] = *reinterpret_cast<const f8 *>(member + ((m >> (8 * h)) & 255u) * 8u);
     };
     auto fma_flagged = [&](unsigned m, const f8 (&F)[QR], const float (&x)[C]) {
+#if defined(SMT_AGG_KNOCKOUT) && SMT_AGG_KNOCKOUT == 1
+        // diagnostic build: every tap is still loaded and waited for, its flags still fetched, one packed FMA per
+        // tap keeps them live -- what is left is the memory side + the scalar bookkeeping of the kernel
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            acc[0][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, f2{F[0][0], F[QR - 1][1]}, acc[0][c]);
+        return;
+#endif
 #pragma unroll
         for (int h = 0; h < QR; h++) {
             const unsigned mb = (m >> (8 * h)) & 255u;
@@ -799,7 +882,7 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
                 const f2 fl = f2{F[h][2 * j], F[h][2 * j + 1]};
 #pragma unroll
                 for (int c = 0; c < C; c++)
-                    acc[4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[4 * h + j][c]);
+                    acc[MFMA ? 0 : 4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[MFMA ? 0 : 4 * h + j][c]);
             };
             if (mb & 0x0fu) { pair(0); pair(1); }
             if (mb & 0xf0u) { pair(2); pair(3); }
@@ -898,7 +981,11 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
-                if (PREF) {
+                if (MFMA) {
+                    __builtin_amdgcn_sched_barrier(0);               // every load of the group is issued before its first use
+#pragma unroll
+                    for (int k = 0; k < GG; k++) mfma_flagged(m[k], x[k]);
+                } else if (PREF) {
                     f8 F[2][QR];
                     load_flags(m[0], F[0]);
 #pragma unroll
@@ -951,7 +1038,7 @@ __global__ void __launch_bounds__(NT, (C <= 3 ? 6 : 4)) k_aggregate_multi(const 
         bool bad = ub;
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            a[k] = (q & 1) ? acc[q / 2][k].y : acc[q / 2][k].x;
+            a[k] = MFMA ? macc[MFMA ? q / 4 : 0][k][q & 3] : ((q & 1) ? acc[MFMA ? 0 : q / 2][k].y : acc[MFMA ? 0 : q / 2][k].x);
             bad = bad || (a[k] != a[k]);
         }
         if (__ballot(bad)) { redo |= 1u << q; continue; }
@@ -1123,6 +1210,7 @@ struct smt_crossarm {
     float *member;       // 256 x 8 membership flags for variant 3
     uint16_t *cand;      // [4][H][W] arm candidates {threshold still tau, already tau_low} (mask-based arm kernels)
     bool arm_walk;       // test hook: use the neighbour-by-neighbour kernels even when the masks apply
+    int occ_lds;         // dynamic LDS bytes per aggregation workgroup, used as an occupancy limiter (see smt_crossarm_set_occupancy)
 };
 
 SMT_API void smt_crossarm_default_params(smt_crossarm_params *p)
@@ -1144,6 +1232,12 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
     h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 7;
+    {
+        // default: 4 workgroups (= 4 waves per SIMD) per CU, see smt_crossarm_set_occupancy; SMT_AGG_WAVES overrides
+        static const int env_waves = [] { const char *e = getenv("SMT_AGG_WAVES"); return e ? atoi(e) : -1; }();
+        const int waves = env_waves >= 0 ? env_waves : 4;
+        h->occ_lds = (waves >= 3 && waves <= 5) ? (160 * 1024 / waves - 512) & ~255 : 0;   // <= 64 KB: no attribute needed
+    }
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
     if (h->P.sec_length < 0 || h->P.max_length < 0 || h->P.max_length > 4096) { delete h; return SMT_ERR_ARG; }
     int rc = SMT_OK;
@@ -1332,7 +1426,7 @@ static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, flo
     const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
 #define SMT_AGGM(CC, FF)                                                                                  \
-    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP>), grid, dim3(NT), 0, h->stream, vin, vout, h->H, h->W, \
+    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP>), grid, dim3(NT), (size_t)h->occ_lds, h->stream, vin, vout, h->H, h->W, \
                        h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member, h->sweep)
     switch (C * 2 + (full ? 1 : 0)) {
     case 2: SMT_AGGM(1, false); break;
@@ -1444,6 +1538,10 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 5) { if (order == 0) launch_agg_multi<0, 2, 0>(h, vin, vout, disp); else launch_agg_multi<1, 2, 0>(h, vin, vout, disp); }
     else if (variant == 6) { if (order == 0) launch_agg_multi<0, 2, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 2>(h, vin, vout, disp); }
     else if (variant == 7) { if (order == 0) launch_agg_multi<0, 2, 3>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3>(h, vin, vout, disp); }
+    else if (variant == 8) { if (order == 0) launch_agg_multi<0, 2, 4>(h, vin, vout, disp); else launch_agg_multi<1, 2, 4>(h, vin, vout, disp); }
+    else if (variant == 9) { if (order == 0) launch_agg_multi<0, 2, 5>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5>(h, vin, vout, disp); }
+    else if (variant == 10) { if (order == 0) launch_agg_multi<0, 2, 6>(h, vin, vout, disp); else launch_agg_multi<1, 2, 6>(h, vin, vout, disp); }
+    else if (variant == 11) { if (order == 0) launch_agg_multi<0, 2, 7>(h, vin, vout, disp); else launch_agg_multi<1, 2, 7>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1451,12 +1549,12 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 7) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 11) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->variant = variant;
     // the lock-step kernel wants its four waves stacked vertically (8 columns x 8 rows per workgroup: the
     // waves then walk the same columns); the free-running ones measure best with 16-column strips
-    h->strip_w8 = variant == 7 ? 8 : 16;
+    h->strip_w8 = variant >= 7 ? 8 : 16;
     return SMT_OK;
 }
 
@@ -1472,6 +1570,19 @@ SMT_API int smt_crossarm_set_arm_walk(smt_crossarm *h, int on)
 {
     if (!h) return SMT_ERR_ARG;
     h->arm_walk = on != 0;
+    return SMT_OK;
+}
+
+// Aggregation workgroups per CU (= waves per SIMD: a workgroup is four waves, one per SIMD).  The kernel needs 80
+// VGPRs; left alone it runs 6 waves per SIMD = 480 of the 512 VGPRs, and a kernel on another stream (the scanline
+// passes want 96 per wave) never finds room until the aggregation's grid is exhausted -- the two then run one after
+// the other whatever the streams say.  The aggregation itself is flat between 4 and 6 waves per SIMD,
+// so by default every workgroup also claims 1/4 of the CU's LDS it does not use: 4 waves per SIMD, 192 VGPRs per
+// SIMD left for whatever else is running.  waves = 0 removes the limit (6 per SIMD, from the VGPR count).
+SMT_API int smt_crossarm_set_occupancy(smt_crossarm *h, int waves_per_simd)
+{
+    if (!h || !(waves_per_simd == 0 || (waves_per_simd >= 3 && waves_per_simd <= 5))) return SMT_ERR_ARG;
+    h->occ_lds = (waves_per_simd >= 3 && waves_per_simd <= 5) ? (160 * 1024 / waves_per_simd - 512) & ~255 : 0;
     return SMT_OK;
 }
 

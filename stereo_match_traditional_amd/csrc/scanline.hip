@@ -71,11 +71,22 @@ template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
 template <> struct vecf<3> { float v[3]; };
 template <> struct __attribute__((aligned(16))) vecf<4> { float v[4]; };
 
+// Cache policy of the volume traffic (compile-time, A/B builds): SMT_SCAN_NT & 1 = non-temporal loads, & 2 =
+// non-temporal stores.  Every byte a pass touches is used once per pass, so nothing is lost by not keeping it;
+// what it changes is how much of the L2 / Infinity Cache a kernel running BESIDE the scanline keeps.
+#ifndef SMT_SCAN_NT
+#define SMT_SCAN_NT 0
+#endif
 // row of C consecutive floats per lane; FULL (D == 64*C): one unpredicated vector access
 template <int C, bool FULL>
 __device__ __forceinline__ void ld_row(const float *p, int dl, int D, float fill, float (&dst)[C])
 {
     if (FULL) {
+        if (SMT_SCAN_NT & 1) {
+#pragma unroll
+            for (int k = 0; k < C; k++) dst[k] = __builtin_nontemporal_load(p + k);
+            return;
+        }
         const vecf<C> x = *reinterpret_cast<const vecf<C> *>(p);
 #pragma unroll
         for (int k = 0; k < C; k++) dst[k] = x.v[k];
@@ -88,6 +99,11 @@ template <int C, bool FULL>
 __device__ __forceinline__ void st_row(float *p, int dl, int D, const float (&src)[C])
 {
     if (FULL) {
+        if (SMT_SCAN_NT & 2) {
+#pragma unroll
+            for (int k = 0; k < C; k++) __builtin_nontemporal_store(src[k], p + k);
+            return;
+        }
         vecf<C> x;
 #pragma unroll
         for (int k = 0; k < C; k++) x.v[k] = src[k];
