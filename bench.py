@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F64_VECTOR_TFLOPS = 78.6   # dense fp64 vector peak
 F32_ADDS_PER_S = 78.6e12   # fp32 vector peak 157.3 TFLOP/s counts an FMA as 2: plain adds issue at half of it
+SAD_U8_PER_S = 4 * 32 * 1024 * 2.4e9   # v_sad_u8: 4 byte differences + add per lane, 32 lanes per clock per SIMD, 1 024 SIMDs, 2.4 GHz
+LDS_B32_TBS = 75.0         # ds_read_b32 aggregate rate with every CU streaming (MI355X_MICROARCH.md, LDS)
 
 WORKLOADS = {
     # name: (H, W, D, seed, description)
@@ -105,6 +107,22 @@ def pmc_traffic(workload):
         return None, None
 
 
+def pmc_lds(key):
+    """LDS counters of a profiled launch (profiles/pmc_lds.json <- tools/prof_pmc_scanline.sh)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_lds.json")))[key]
+    except Exception:
+        return None
+
+
+def pmc_scanline():
+    """HBM bytes per hypothesis of the three scanline kernels (profiles/pmc_scanline.json, same passes)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_scanline.json")))
+    except Exception:
+        return None
+
+
 def smi_snapshot():
     """Best-effort rocm-smi readings (child process; never fatal): temperatures, clocks, power."""
     # under rocprofv3 the child would inherit the profiler's GPU-initialising preload and then exec rocm-smi's
@@ -154,8 +172,12 @@ def extra_configs(dev, reps=5):
     L, R = synth.synth_pair(H, W, D, 1)
     Lp, Rp = T(np.pad(L, 2, mode="edge")), T(np.pad(R, 2, mode="edge"))
     ms = ev_timed(lambda: smt.GetPointDepthLeft(Lp, Rp, D, 1), 20)
+    taps = 25.0 * H * W * D                               # |a - b| + accumulate per window tap and hypothesis (Sad.h:15-20)
     out["cfg1_sad5x5_450x375_d64"] = {"ms_per_view": round(ms, 4), "Mdisp_s": round(H * W * D / ms / 1e3, 1),
-                                      "bound": "valu-int (volume never stored)"}
+                                      "bound": "valu-int (volume never stored)", "alg_byte_sads_per_view": taps,
+                                      "frac_valu_sad_u8_peak": round(taps / (ms * 1e-3) / SAD_U8_PER_S, 4),
+                                      "note": "10.8 M hypotheses in all: one wave per pixel, ten unaligned dword loads per lane and pixel; "
+                                              "the launch is latency bound, not VALU bound (DESIGN.md 4)"}
 
     # ---- configs 2 and 5: AD-Census both views + WTA ---------------------------------------------
     for key, (H, W, D, seed, P) in {"cfg2_adcensus_720p_d128": (720, 1280, 128, 2, 8),
@@ -221,6 +243,8 @@ def extra_configs(dev, reps=5):
             rec["mean_rect_area"] = round(area[k.split("_")[1]], 2)
             rec["inorder_adds"] = adds
             rec["frac_f32_add_peak"] = round(adds / (ms * 1e-3) / F32_ADDS_PER_S, 4)
+        if k == "scanline" and pmc_scanline():
+            rec["hbm_traffic_profiled"] = pmc_scanline()
         stages[k] = rec
     out["cfg3_pipeline_1080p_d192"] = {
         "ms_per_pair": round(total, 4), "Mdisp_s": round(V / total / 1e3, 1), "alg_bytes_per_hyp": 68,
@@ -245,8 +269,15 @@ def extra_configs(dev, reps=5):
         L, R = synth.synth_pair(H, W, 64, 1)
         Lt, Rt = T(L), T(R)
         ms = ev_timed(lambda: smt.NCC_algorithem(Lt, Rt, win, Dn), 3)
-        out[f"a23_ncc21x21_450x375_d{Dn}"] = {"ms": round(ms, 4), "Mdisp_s": round((H - 2 * win) * (W - 2 * win) * Dn / ms / 1e3, 1),
-                                                "bound": "lds (G + K - 1 ds_read_b32 per window row for the K slots of a lane + one broadcast read per v_dot4_u32_u8)"}
+        rec = {"ms": round(ms, 4), "Mdisp_s": round((H - 2 * win) * (W - 2 * win) * Dn / ms / 1e3, 1),
+               "bound": "lds (G + K - 1 ds_read_b32 per window row for the K slots of a lane + one broadcast read per v_dot4_u32_u8)"}
+        lds = pmc_lds(f"ncc21x21_450x375_d{Dn}")
+        if lds:
+            # LDS wave-instructions of the k_ncc2 launch (rocprofv3 SQ_INSTS_LDS, committed) x 256 B each, over this run's time
+            rec.update({"lds_wave_instructions": lds["SQ_INSTS_LDS"], "lds_bytes": lds["SQ_INSTS_LDS"] * 256.0,
+                        "frac_lds_b32_peak": round(lds["SQ_INSTS_LDS"] * 256.0 / (ms * 1e-3) / (LDS_B32_TBS * 1e12), 4),
+                        "lds_array_busy_frac_profiled": lds.get("lds_array_busy"), "lds_source": lds.get("source")})
+        out[f"a23_ncc21x21_450x375_d{Dn}"] = rec
 
     # ---- CrossAggregator (named in north_star): 4 iterations x 2 passes at 1280x720, D=128 ----
     H, W, D = 720, 1280, 128

@@ -66,11 +66,17 @@ int smt_set_device(int device);
  * device.  The stateless entry points (smt_wta, smt_lrcheck, smt_sad, ...) run on the device that is
  * current in the calling thread.
  *
- * Limits (the reference has none; outside them SMT_ERR_ARG):  dispRange D <= 256 on every entry point
- * (one wavefront spans the disparity axis, at most 4 hypotheses per lane); ASW window side
+ * Limits (the reference has none; outside them SMT_ERR_ARG):  dispRange D <= SMT_MAX_DISPARITY = 512 on the
+ * AD-Census pipeline (smt_adcensus_*, smt_wta, smt_crossarm_*, smt_scanline_*, smt_pipeline_*: one wavefront
+ * spans the disparity axis, a lane owns up to 8 consecutive hypotheses; the tuned kernels cover D <= 256, beyond
+ * it the first-version kernels run -- the table-lookup cost kernel, the one-pixel-per-wave rectangle walk, the
+ * predicated scanline passes -- with the same results, untuned) and D <= 256 on the window matchers, the
+ * CrossAggregator and the CBLSM helpers (smt_sad, smt_ncc, smt_asw, smt_crossagg_*, smt_cblsm_*); ASW window side
  * 2*(winSize+1)+1 <= 64 (winSize <= 30; one window row per wavefront pass); MedianFilter wnd_size <= 7;
  * volumes of 4 GiB or more take the plain one-pixel-per-wave aggregation kernel (32-bit tap offsets in
  * the shared-tap kernels). */
+
+#define SMT_MAX_DISPARITY 512
 
 /* ---- device memory helpers (plumbing; not part of the reference's surface) ---------- */
 int smt_malloc(void **dptr, size_t bytes);
@@ -508,7 +514,8 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
             void *stream);
 /* Scratch device memory of smt_asw / smt_ncc comes from an arena the library owns (csrc/scratch.hip: hipMalloc'ed
  * blocks cached per device and handed out stream-ordered on the caller's stream).  The arena keeps what it has grown
- * to -- the anchor table of an smt_asw call, 24*H*W bytes after an smt_ncc -- until the process ends or the host asks
+ * to -- the anchor-weight slots of an smt_asw call (one per workgroup in flight: 512 x 32 x (2*winSize+3)^2 x 8
+ * bytes, 160 MB at 35 x 35, whatever the image size), 24*H*W bytes after an smt_ncc -- until the process ends or the host asks
  * for it back: smt_scratch_trim synchronises the current device and returns every idle block beyond `keep_bytes` to
  * the driver (hipFree); smt_scratch_info reports what the arena holds / has handed out.
  * Why not hipMallocAsync: on ROCm 7.2 a stream-ordered pool that trims and grows again hands out a block that is
@@ -517,11 +524,12 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
  * device's default pool (the failing configuration) / plain hipMalloc per call. */
 int smt_scratch_trim(size_t keep_bytes);
 int smt_scratch_info(size_t *reserved_bytes, size_t *used_bytes);
-/* Test hook (process-wide): 3 = anchor-weight table + per-row other-image weight tables in LDS (default; needs
- * H*W*(2*winSize+3)^2*8 bytes of scratch device memory for the duration of the call, stream-ordered; a wave
- * carries two pixels), 4 = the same with one pixel per wave, 5 = as 3 with the anchor operands read by vector
- * loads instead of through the scalar cache,
- * 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
+/* Test hook (process-wide): which ASW formulation runs.  6 (default) = per-row other-image weight tables in LDS and
+ * the anchor weights in one scratch slot per workgroup in flight, rebuilt by the workgroup for every tile it takes
+ * (k_asw4; scratch independent of the image size); 3 = the same tap loop over a whole-image anchor table written by
+ * a table kernel first (H*W*(2*winSize+3)^2*8 bytes of scratch: 5 GB at 960x540, 35x35), two pixels per wave;
+ * 4 = 3 with one pixel per wave; 5 = 3 with the anchor operands read by vector loads instead of through the scalar
+ * cache; 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
  * All produce identical bits. */
 int smt_asw_set_impl(int impl);
 /* Batch variants of the three window matchers ("batch variants taking a pair count and strides"):

@@ -750,7 +750,7 @@ def asw_batch(leftGrays, rightGrays, winSize, dispRange, space, color, T, view=V
 
 
 def asw_set_impl(impl):
-    """3 = table-driven ASW kernels (default), 1 = first formulation (test hook)."""
+    """6 = per-workgroup anchor slots (default), 3 / 4 / 5 = whole-image anchor table variants, 1 = first formulation (test hook)."""
     check(lib().smt_asw_set_impl(int(impl)), "smt_asw_set_impl")
 
 

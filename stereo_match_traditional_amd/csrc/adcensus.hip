@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, cons
     }
 }
 
-template <int C> struct vecf;
+template <int C> struct vecf { float v[C]; };          // C = 5..8 (D > 256): plain struct, the kernels there use the per-element paths
 template <> struct vecf<1> { float v[1]; };
 template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
 template <> struct vecf<3> { float v[3]; };
@@ -876,7 +876,7 @@ SMT_API int smt_adcensus_placement(smt_adcensus *h, int *tries, float *store_onl
 
 static int adcensus_create(int H, int W, int D, float sigmaC, float sigmaS, unsigned flags, smt_adcensus **out)
 {
-    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256 || !(sigmaC > 0.0f) || !(sigmaS > 0.0f))
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > SMT_MAX_DISPARITY || !(sigmaC > 0.0f) || !(sigmaS > 0.0f))
         return SMT_ERR_ARG;
     smt_adcensus *h = new (std::nothrow) smt_adcensus();
     if (!h) return SMT_ERR_ALLOC;
@@ -1061,12 +1061,18 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     const int nviews = (views == SMT_VIEW_BOTH) ? 2 : 1;
     const int C = (D + 63) / 64;
     const bool full = (D % 64) == 0;
-    if (h->force_generic) {
-        switch (C) {                                       // the table-lookup kernel of the first version,
-        case 1: launch_cost<1, false>(h, view0, nviews, dL, dR); break;   // kept as an independent formulation
+    if (h->force_generic || C > 4) {
+        // the table-lookup kernel of the first version: kept as an independent formulation, and the kernel for
+        // 256 < D <= 512 (a lane then owns 5..8 consecutive hypotheses; the register-window kernel stops at 4)
+        switch (C) {
+        case 1: launch_cost<1, false>(h, view0, nviews, dL, dR); break;
         case 2: launch_cost<2, false>(h, view0, nviews, dL, dR); break;
         case 3: launch_cost<3, false>(h, view0, nviews, dL, dR); break;
-        default: launch_cost<4, false>(h, view0, nviews, dL, dR); break;
+        case 4: launch_cost<4, false>(h, view0, nviews, dL, dR); break;
+        case 5: launch_cost<5, false>(h, view0, nviews, dL, dR); break;
+        case 6: launch_cost<6, false>(h, view0, nviews, dL, dR); break;
+        case 7: launch_cost<7, false>(h, view0, nviews, dL, dR); break;
+        default: launch_cost<8, false>(h, view0, nviews, dL, dR); break;
         }
     } else {
         switch (C * 2 + (full ? 1 : 0)) {
@@ -1286,12 +1292,12 @@ SMT_API int smt_adcensus_diag(smt_adcensus *h, int reps, float *sclk_mhz, float 
 
 SMT_API int smt_wta(const float *vol, int H, int W, int D, float *disp, void *stream)
 {
-    if (!vol || !disp || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    if (!vol || !disp || H <= 0 || W <= 0 || D <= 0 || D > SMT_MAX_DISPARITY) return SMT_ERR_ARG;
     const int N = H * W;
     dim3 grid((N + 3) / 4);
     const int C = (D + 63) / 64;
     hipStream_t st = smt_stream(stream);
-    const bool full = (D == 64 * C);
+    const bool full = (D == 64 * C) && C <= 4;
 #define SMT_WTA(CC)                                                                                  \
     do {                                                                                             \
         if (full) hipLaunchKernelGGL((k_wta<CC, true>), grid, dim3(NT), 0, st, vol, N, D, disp);     \
@@ -1301,7 +1307,11 @@ SMT_API int smt_wta(const float *vol, int H, int W, int D, float *disp, void *st
     case 1: SMT_WTA(1); break;
     case 2: SMT_WTA(2); break;
     case 3: SMT_WTA(3); break;
-    default: SMT_WTA(4); break;
+    case 4: SMT_WTA(4); break;
+    case 5: hipLaunchKernelGGL((k_wta<5, false>), grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    case 6: hipLaunchKernelGGL((k_wta<6, false>), grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    case 7: hipLaunchKernelGGL((k_wta<7, false>), grid, dim3(NT), 0, st, vol, N, D, disp); break;
+    default: hipLaunchKernelGGL((k_wta<8, false>), grid, dim3(NT), 0, st, vol, N, D, disp); break;
     }
 #undef SMT_WTA
     SMT_LAUNCH_CHECK();

@@ -240,7 +240,7 @@ __global__ void k_tau_update(const int *__restrict__ flip, int dir0, int ndir, i
         if (flip[e] != INT_MAX) *tau_state = tau_low;
 }
 
-template <int C> struct vecf;
+template <int C> struct vecf { float v[C]; };          // C = 5..8 (D > 256)
 template <> struct vecf<1> { float v[1]; };
 template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
 template <> struct vecf<3> { float v[3]; };
@@ -666,12 +666,15 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     // 5 = the same with the group-skip branches kept.  6 = 4 with ONE A register per tap: lane l < 16 carries the flag
     // of pixel l, and the instruction's A-broadcast field (CBSZ = 4: all 16 blocks read the A values of block ABID)
     // picks group g's four lanes -- two VALU operations per tap instead of two per group.
-    constexpr bool MFMA = (SKIP >= 4);
-    static_assert(SKIP <= 7, "");
+    constexpr bool MFMA = (SKIP >= 4 && SKIP <= 6);
+    static_assert(SKIP <= 7 && (SKIP != 7 || QR == 2), "");
     constexpr bool MSKIP = (SKIP == 5);
     constexpr bool MBCAST = (SKIP == 6);
-    constexpr bool MHACK = (SKIP == 7);                  // TIMING EXPERIMENT ONLY (results wrong): 3 x 16x16x4 per tap
-    constexpr bool SYNC = (SKIP >= 3);
+    // 7 ("both pipes"): the upper row of the 2x8 tile accumulates on the matrix pipe (6 MFMA per tap, A broadcast, no
+    // branch), the lower row on the vector pipe as in SKIP == 3 (flag row fetched one tap ahead, two group-skip
+    // branches): the two halves of a tap's FMAs issue to different pipes, which run side by side across waves.
+    constexpr bool HYB = (SKIP == 7);
+    constexpr bool SYNC = (SKIP >= 3);                   // 3 .. 7 all walk in lock-step
     constexpr bool PREF = (SKIP >= 2);                   // flag rows fetched one tap ahead + per-axis tables
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -747,13 +750,13 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     const int dl = lane * C;
     typedef float f4 __attribute__((ext_vector_type(4)));
     f2 acc[MFMA ? 1 : NPIX / 2][C];
-    f4 macc[MFMA ? NPIX / 4 : 1][C];                       // matrix formulation: group g = pixels 4g .. 4g + 3, register i = pixel 4g + i
+    f4 macc[(MFMA || HYB) ? NPIX / 4 : 1][C];              // matrix formulation: group g = pixels 4g .. 4g + 3, register i = pixel 4g + i
 #pragma unroll
     for (int j = 0; j < (MFMA ? 1 : NPIX / 2); j++)
 #pragma unroll
         for (int k = 0; k < C; k++) acc[j][k] = f2{0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < (MFMA ? NPIX / 4 : 1); j++)
+    for (int j = 0; j < ((MFMA || HYB) ? NPIX / 4 : 1); j++)
 #pragma unroll
         for (int k = 0; k < C; k++) macc[j][k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     // bit of the membership mask that lane l turns into its A operand for group g: 4g + (l & 3)
@@ -761,23 +764,9 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
 #pragma unroll
     for (int g = 0; g < (MFMA ? NPIX / 4 : 1); g++) mshift[g] = 4 * g + (lane & 3);
     const int mshift16 = lane & 15;
-    int hack_rot = 0;
     auto mfma_flagged = [&](unsigned m, const float (&x)[C]) {
-        if (MHACK) {
-            // same matrix-pipe time per tap as twelve 4x4x1 (3 x 32 cycles), a quarter of the instructions; 12 live accumulators
-            const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int g = (hack_rot + c) & 3;
-                if (g == 0) macc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[0][c], 0, 0, 0);
-                else if (g == 1) macc[NPIX > 4 ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 4 ? 1 : 0][c], 0, 0, 0);
-                else if (g == 2) macc[NPIX > 8 ? 2 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 8 ? 2 : 0][c], 0, 0, 0);
-                else macc[NPIX > 8 ? 3 : 0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, x[c], macc[NPIX > 8 ? 3 : 0][c], 0, 0, 0);
-            }
-            hack_rot++;
-            return;
-        }
-        if (MBCAST) {
+        if constexpr (!MFMA) return;
+        if constexpr (MBCAST) {
             const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -797,7 +786,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
                 for (int c = 0; c < C; c++)
                     macc[MFMA ? g : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA ? g : 0][c], 0, 0, 0);
             };
-            if (!MSKIP) body();
+            if constexpr (!MSKIP) body();
             else if ((m >> (4 * g)) & 15u) body();
         }
     };
@@ -887,6 +876,25 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
             if (mb & 0x0fu) { pair(0); pair(1); }
             if (mb & 0xf0u) { pair(2); pair(3); }
         }
+    };
+
+    auto hyb_flagged = [&](unsigned m, const f8 &F1, const float (&x)[C]) {
+        if constexpr (!HYB) return;
+        const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);   // lanes 0..7: the upper row's flags
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            macc[0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[0][c], 4, 0, 0);
+            macc[HYB ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[HYB ? 1 : 0][c], 4, 1, 0);
+        }
+        const unsigned mb = (m >> 8) & 255u;
+        auto pair = [&](int j) {
+            const f2 fl = f2{F1[2 * j], F1[2 * j + 1]};
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                acc[HYB ? 4 + j : 0][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[HYB ? 4 + j : 0][c]);
+        };
+        if (mb & 0x0fu) { pair(0); pair(1); }
+        if (mb & 0xf0u) { pair(2); pair(3); }
     };
 
     // box whose positions are enumerated: the wave's own bounding box, or (SYNC) the common one of the four
@@ -981,11 +989,22 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
-                if (MFMA) {
+                if constexpr (HYB) {
+                    f8 F1[2];
+                    F1[0] = *reinterpret_cast<const f8 *>(member + ((m[0] >> 8) & 255u) * 8u);
+#pragma unroll
+                    for (int k = 0; k < GG; k++) {
+                        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this tap's flag row is in
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (k + 1 < GG) F1[(k + 1) & 1] = *reinterpret_cast<const f8 *>(member + ((m[k + 1] >> 8) & 255u) * 8u);
+                        __builtin_amdgcn_sched_barrier(0);
+                        hyb_flagged(m[k], F1[k & 1], x[k]);
+                    }
+                } else if constexpr (MFMA) {
                     __builtin_amdgcn_sched_barrier(0);               // every load of the group is issued before its first use
 #pragma unroll
                     for (int k = 0; k < GG; k++) mfma_flagged(m[k], x[k]);
-                } else if (PREF) {
+                } else if constexpr (PREF) {
                     f8 F[2][QR];
                     load_flags(m[0], F[0]);
 #pragma unroll
@@ -1038,7 +1057,8 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
         bool bad = ub;
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            a[k] = MFMA ? macc[MFMA ? q / 4 : 0][k][q & 3] : ((q & 1) ? acc[MFMA ? 0 : q / 2][k].y : acc[MFMA ? 0 : q / 2][k].x);
+            a[k] = (MFMA || (HYB && q < 8)) ? macc[(MFMA || (HYB && q < 8)) ? q / 4 : 0][k][q & 3]
+                                            : ((q & 1) ? acc[MFMA ? 0 : q / 2][k].y : acc[MFMA ? 0 : q / 2][k].x);
             bad = bad || (a[k] != a[k]);
         }
         if (__ballot(bad)) { redo |= 1u << q; continue; }
@@ -1227,7 +1247,7 @@ SMT_API void smt_crossarm_cblsm_params(smt_crossarm_params *p)
 
 SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *p, smt_crossarm **out)
 {
-    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > SMT_MAX_DISPARITY) return SMT_ERR_ARG;
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
@@ -1481,7 +1501,11 @@ static void launch_agg(smt_crossarm *h, const float *vin, float *vout, float *di
     case 1: SMT_AGG(1); break;
     case 2: SMT_AGG(2); break;
     case 3: SMT_AGG(3); break;
-    default: SMT_AGG(4); break;
+    case 4: SMT_AGG(4); break;
+    case 5: SMT_AGG(5); break;
+    case 6: SMT_AGG(6); break;
+    case 7: SMT_AGG(7); break;
+    default: SMT_AGG(8); break;
     }
 #undef SMT_AGG
 }
@@ -1530,6 +1554,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     // walk.  All but 1 address taps with 32-bit byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
+    if (h->D > 256) variant = 1;                          // 5..8 hypotheses per lane: the plain walk only
     if (order == 2) { launch_agg<2>(h, vin, vout, disp); SMT_LAUNCH_CHECK(); return SMT_OK; }   // inactive sibling: plain walk only
     if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }

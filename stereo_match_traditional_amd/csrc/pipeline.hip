@@ -90,7 +90,7 @@ static int pipeline_apply_streams(smt_pipeline *h)
 
 SMT_API int smt_pipeline_create(int H, int W, int D, const smt_pipeline_params *p, smt_pipeline **out)
 {
-    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > SMT_MAX_DISPARITY) return SMT_ERR_ARG;
     smt_pipeline *h = new (std::nothrow) smt_pipeline();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();

@@ -65,7 +65,7 @@ struct ScanArgs {
     float p1, p2;
 };
 
-template <int C> struct vecf;
+template <int C> struct vecf { float v[C]; };          // C = 5..8 (D > 256)
 template <> struct vecf<1> { float v[1]; };
 template <> struct __attribute__((aligned(8))) vecf<2> { float v[2]; };
 template <> struct vecf<3> { float v[3]; };
@@ -273,7 +273,7 @@ struct smt_scanline {
 
 SMT_API int smt_scanline_create(int H, int W, int D, int p1, int p2, smt_scanline **out)
 {
-    if (!out || H <= 0 || W <= 0 || D <= 0 || D > 256) return SMT_ERR_ARG;
+    if (!out || H <= 0 || W <= 0 || D <= 0 || D > SMT_MAX_DISPARITY) return SMT_ERR_ARG;
     smt_scanline *h = new (std::nothrow) smt_scanline();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
@@ -320,12 +320,13 @@ static void launch_scan2(smt_scanline *h, int pass, const ScanArgs &a)
 template <int C>
 static void launch_scan(smt_scanline *h, int pass, const ScanArgs &a, int mode)
 {
-    const bool full = (h->D == 64 * C);
+    const bool full = (h->D == 64 * C) && C <= 4;         // 5..8 hypotheses per lane (D > 256): the predicated form only
     if (full) {
-        if (mode == 0) launch_scan2<C, 0, true>(h, pass, a);
-        else if (mode == 1) launch_scan2<C, 1, true>(h, pass, a);
-        else if (mode == 2) launch_scan2<C, 2, true>(h, pass, a);
-        else launch_scan2<C, 3, true>(h, pass, a);
+        constexpr int CF = C <= 4 ? C : 1;                // the vector form is never instantiated for C > 4
+        if (mode == 0) launch_scan2<CF, 0, true>(h, pass, a);
+        else if (mode == 1) launch_scan2<CF, 1, true>(h, pass, a);
+        else if (mode == 2) launch_scan2<CF, 2, true>(h, pass, a);
+        else launch_scan2<CF, 3, true>(h, pass, a);
     } else {
         if (mode == 0) launch_scan2<C, 0, false>(h, pass, a);
         else if (mode == 1) launch_scan2<C, 1, false>(h, pass, a);
@@ -338,7 +339,7 @@ template <int C>
 static void launch_lr(smt_scanline *h, const ScanArgs &a)
 {
     dim3 grid((h->H + 3) / 4, 2);
-    if (h->D == 64 * C) hipLaunchKernelGGL((k_scan_lr<C, true>), grid, dim3(NT), 0, h->stream, a);
+    if (C <= 4 && h->D == 64 * C) hipLaunchKernelGGL((k_scan_lr<(C <= 4 ? C : 1), true>), grid, dim3(NT), 0, h->stream, a);
     else hipLaunchKernelGGL((k_scan_lr<C, false>), grid, dim3(NT), 0, h->stream, a);
 }
 
@@ -348,7 +349,11 @@ static int scan_pass(smt_scanline *h, const ScanArgs &a, int pass, int mode)
     case 1: launch_scan<1>(h, pass, a, mode); break;
     case 2: launch_scan<2>(h, pass, a, mode); break;
     case 3: launch_scan<3>(h, pass, a, mode); break;
-    default: launch_scan<4>(h, pass, a, mode); break;
+    case 4: launch_scan<4>(h, pass, a, mode); break;
+    case 5: launch_scan<5>(h, pass, a, mode); break;
+    case 6: launch_scan<6>(h, pass, a, mode); break;
+    case 7: launch_scan<7>(h, pass, a, mode); break;
+    default: launch_scan<8>(h, pass, a, mode); break;
     }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -375,7 +380,11 @@ SMT_API int smt_scanline_run(smt_scanline *h, const float *vin, const float *gra
     case 1: launch_lr<1>(h, a); break;
     case 2: launch_lr<2>(h, a); break;
     case 3: launch_lr<3>(h, a); break;
-    default: launch_lr<4>(h, a); break;
+    case 4: launch_lr<4>(h, a); break;
+    case 5: launch_lr<5>(h, a); break;
+    case 6: launch_lr<6>(h, a); break;
+    case 7: launch_lr<7>(h, a); break;
+    default: launch_lr<8>(h, a); break;
     }
     SMT_LAUNCH_CHECK();
     int rc = scan_pass(h, a, 2, 3);                                        // vout = (left + right) + up

@@ -550,20 +550,26 @@ __global__ void __launch_bounds__(ANT) k_asw(const uint8_t *__restrict__ Lp, con
 // holds the same float64 products w0*space^2, and sw / sv accumulate the taps in the same order.
 constexpr int A3P = 16;                                   // pixels (waves) per workgroup
 
-__global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ Ap, int H, int W, int wins,
+// the anchor image as one dword (float bits) per pixel: scalar / uniform loads want 4-byte elements, and the truncated
+// error is formed in f32 (exact small integers)
+__global__ void __launch_bounds__(256) k_asw_a32(const uint8_t *__restrict__ Ap, size_t n, unsigned *__restrict__ a32)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256)
+        a32[k] = __float_as_uint((float)Ap[k]);
+}
+
+// anchor weights of the rows [i0, i0 + nrows) of the image: table entry ((io - i0) * W + jo) * side^2 + tap
+__global__ void __launch_bounds__(256) k_asw_anchor(const uint8_t *__restrict__ Ap, int i0, int nrows, int W, int wins,
                                                     const double *__restrict__ space, const double *__restrict__ color,
-                                                    double *__restrict__ w0, unsigned *__restrict__ a32)
+                                                    double *__restrict__ w0)
 {
     // one wave per pixel, 4 pixels per workgroup; the wave walks the pixel's side*side taps 64 at a time, so its
     // stores are whole 512-byte pieces of the table
-    const int side = 2 * wins + 1, Wp = W + 2 * wins, Hp = H + 2 * wins;
+    const int side = 2 * wins + 1, Wp = W + 2 * wins;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // one dword per anchor pixel (scalar / uniform loads want 4-byte elements)
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Hp * Wp; k += (size_t)gridDim.x * 256)
-        a32[k] = __float_as_uint((float)Ap[k]);           // as float: the truncated error is formed in f32 (exact small integers)
-    const size_t p = (size_t)blockIdx.x * 4 + wv;
-    if (p >= (size_t)H * W) return;
-    const int io = (int)(p / W), jo = (int)(p % W);
+    const size_t p = (size_t)blockIdx.x * 4 + wv;           // pixel of the band
+    if (p >= (size_t)nrows * W) return;
+    const int io = i0 + (int)(p / W), jo = (int)(p % W);
     const uint8_t *A = Ap + (size_t)io * Wp + jo;
     const int ca = A[wins * Wp + wins];
     const int ntap = side * side;
@@ -635,24 +641,28 @@ __device__ __forceinline__ P uniform_ptr(P p)
 // A3Q = pixels per wave: the per-row tables are built once for A3P * A3Q pixels
 // SLOAD = false (smt_asw_set_impl(5)) reads the two anchor operands with ordinary vector loads from the same
 // wave-uniform addresses instead of s_load: same arithmetic, same results, one more formulation for bisecting.
-template <int K, int A3Q, bool SLOAD = true>
-__global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
-                                                   int W, int D, int wins, const double *__restrict__ color,
-                                                   const double *__restrict__ w0, const unsigned *__restrict__ a32, int T,
-                                                   int view, float *__restrict__ disp, float *__restrict__ cost_out)
+// One tile = NPX consecutive pixels of image row io, starting at column jo0.  OWN = false: w0 is the anchor table of
+// the rows [i0, ...) written by k_asw_anchor.  OWN = true (k_asw4): w0 is this workgroup's private slot
+// ([A3P waves][A3Q pixels][side^2] doubles) and every wave first writes the anchor weights of its own pixels there --
+// the arithmetic of k_asw_anchor -- then reads them back through the scalar cache: vector stores, s_waitcnt vmcnt(0)
+// (the stores have reached L2), s_dcache_inv (the scalar cache may hold the previous tile's slot contents), scalar loads.
+// No other wave ever touches a wave's part of the slot, so no barrier is involved.
+template <int K, int A3Q, bool SLOAD, bool OWN>
+__device__ __forceinline__ void asw3_tile(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                          int W, int D, int wins, const double *__restrict__ space,
+                                          double *w0, const unsigned *__restrict__ a32, int T,
+                                          int view, float *__restrict__ disp, float *__restrict__ cost_out, int i0, int io, int jo0,
+                                          unsigned char *smem)
 {
     constexpr int NPX = A3P * A3Q;                         // pixels per workgroup
     constexpr int NXP = NPX + 64 * K;                      // window positions of the other image per row (padded)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int side = 2 * wins + 1, Wp = W + 2 * wins;
     double *s_T = (double *)smem;                          // [NXP][side]
-    double *s_color = s_T + (size_t)side * NXP;            // [256]
+    double *s_color = s_T + (size_t)side * NXP;            // [256], filled by the caller
     float *s_P = (float *)(s_color + 256);                 // [NXP + side]: the other image's current window row as floats
-    for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int io = blockIdx.y, jo0 = blockIdx.x * NPX;
     // the other image and the first window position the workgroup can touch:
     //   view 0: xs = jo - dd in [jo0 - (D-1), jo0 + NPX-1];   view 1: xs = jo + dd in [jo0, jo0 + NPX-1 + D-1]
     const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
@@ -674,7 +684,23 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
         live[q] = jo[q] < W;
         const int jc = live[q] ? jo[q] : W - 1;
         dmax[q] = (view == 0) ? jc : (W - wins - 2 - jc);  // last in-range disparity (ASW.h:348 / :401)
-        wrow[q] = (cdouble_p)(w0 + ((size_t)io * W + jc) * side * side);
+        double *wtab = OWN ? w0 + ((size_t)wv * A3Q + q) * side * side : w0 + ((size_t)(io - i0) * W + jc) * side * side;
+        wrow[q] = (cdouble_p)wtab;
+        if (OWN) {
+            // this pixel's anchor weights: color[|A(q) - A(centre)|] * space(q)^2, the two products of k_asw in its order
+            const uint8_t *A = (view == 0 ? Lp : Rp) + (size_t)io * Wp + jc;
+            const int ca = A[wins * Wp + wins];
+            const int ntap = side * side;
+            const float rs = 1.0f / (float)side;
+            for (int t = lane; t < ntap; t += 64) {
+                int r = (int)((float)t * rs);              // t / side, corrected below
+                int c = t - r * side;
+                if (c < 0) { r--; c += side; }
+                if (c >= side) { r++; c -= side; }
+                const double sp = space[t];
+                wtab[t] = s_color[abs((int)A[r * Wp + c] - ca)] * (sp * sp);
+            }
+        }
         arow[q] = (cunsigned_p)(a32 + (size_t)io * Wp + jc);
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -684,6 +710,18 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
             tk[q][k] = s_T + (size_t)(xs - xbase) * side;  // row e of T[e][c]: the row stride (side, odd) keeps b64 reads conflict-free
             pk[q][k] = s_P + (xs - xbase);
             sw[q][k] = 0.0; sv[q][k] = 0.0;
+        }
+    }
+    if (OWN) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the table stores have completed (L2 has them)
+        __builtin_amdgcn_s_dcache_inv();                   // the scalar cache may still hold this slot's previous contents
+        // the loads below go through constant-address-space pointers, which the compiler may treat as never written:
+        // make the pointers opaque here so that no load of the table can be scheduled above this point
+#pragma unroll
+        for (int q = 0; q < A3Q; q++) {
+            uint64_t v = (uint64_t)wrow[q];
+            asm volatile("" : "+v"(v) : : "memory");
+            wrow[q] = (cdouble_p)v;
         }
     }
     const float Tf = (float)T;
@@ -714,7 +752,8 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
         for (int q = 0; q < A3Q; q++) {
             cdouble_p wr = uniform_ptr(wrow[q] + r * side);   // wave-uniform operands through the scalar cache
             cunsigned_p ar = uniform_ptr(arow[q] + (size_t)r * Wp);
-            const double *wrv = w0 + (((size_t)io * W + (live[q] ? jo[q] : W - 1)) * side + r) * side;
+            const double *wrv = (OWN ? w0 + ((size_t)wv * A3Q + q) * side * side
+                                     : w0 + ((size_t)(io - i0) * W + (live[q] ? jo[q] : W - 1)) * side * side) + (size_t)r * side;
             const unsigned *arv = a32 + ((size_t)io + r) * Wp + (live[q] ? jo[q] : W - 1);
             auto tap = [&](int c) {
                 const double w = SLOAD ? wr[c] : __builtin_nontemporal_load(wrv + c);
@@ -764,12 +803,53 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const
     }
 }
 
+template <int K, int A3Q, bool SLOAD = true>
+__global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw3(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                                   int W, int D, int wins, const double *__restrict__ color,
+                                                   const double *__restrict__ w0, const unsigned *__restrict__ a32, int T,
+                                                   int view, float *__restrict__ disp, float *__restrict__ cost_out, int i0)
+{
+    // i0: first image row of this launch's band; w0 holds the anchor weights of the band's rows only
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NPX = A3P * A3Q, NXP = NPX + 64 * K;
+    double *s_color = (double *)smem + (size_t)(2 * wins + 1) * NXP;
+    for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
+    asw3_tile<K, A3Q, SLOAD, false>(Lp, Rp, H, W, D, wins, nullptr, const_cast<double *>(w0), a32, T, view, disp, cost_out, i0,
+                                    i0 + (int)blockIdx.y, (int)blockIdx.x * NPX, smem);
+}
+
+// The same tiles from a fixed number of workgroups that each own one slot of anchor-weight scratch (fourth
+// formulation, default): workgroup b takes tiles b, b + gridDim.x, ... of the row-major tile order and rebuilds its
+// slot for every tile, so the anchor table is O(workgroups in flight) -- 160 MB at 35 x 35 whatever the image size --
+// instead of O(image) (5 GB at 960 x 540), and no separate table kernel runs.  Results are those of k_asw3, bit for bit.
+template <int K, int A3Q>
+__global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw4(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H,
+                                                   int W, int D, int wins, const double *__restrict__ space, const double *__restrict__ color,
+                                                   double *__restrict__ slots, const unsigned *__restrict__ a32, int T,
+                                                   int view, float *__restrict__ disp, float *__restrict__ cost_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NPX = A3P * A3Q, NXP = NPX + 64 * K;
+    const int side = 2 * wins + 1;
+    double *s_color = (double *)smem + (size_t)side * NXP;
+    for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
+    __syncthreads();                                       // the anchor phase of the first tile reads s_color
+    const int tpr = (W + NPX - 1) / NPX, ntiles = tpr * H;
+    double *slot = slots + (size_t)blockIdx.x * NPX * side * side;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asw3_tile<K, A3Q, true, true>(Lp, Rp, H, W, D, wins, space, slot, a32, T, view, disp, cost_out, 0, tile / tpr,
+                                      (tile % tpr) * NPX, smem);
+        __syncthreads();                                   // the tile's LDS tables are no longer read
+    }
+}
+
+
 }  // namespace
 
-static int g_asw_impl = 3;   // 3: k_asw_anchor + k_asw3, two pixels per wave (default); 4: one pixel per wave; 5: as 3 with vector loads of the anchor operands; 1: k_asw (first formulation)
+static int g_asw_impl = 6;   // 6: k_asw4, anchor weights in per-workgroup slots (default); 3: k_asw_anchor + k_asw3 over a whole-image table, two pixels per wave; 4: one pixel per wave; 5: as 3 with vector loads of the anchor operands; 1: k_asw (first formulation)
 SMT_API int smt_asw_set_impl(int impl)
 {
-    if (impl != 1 && impl != 3 && impl != 4 && impl != 5) return SMT_ERR_ARG;
+    if (impl != 1 && impl != 3 && impl != 4 && impl != 5 && impl != 6) return SMT_ERR_ARG;
     g_asw_impl = impl;
     return SMT_OK;
 }
@@ -885,21 +965,34 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     const int impl = env_impl ? env_impl : g_asw_impl;
     if (impl >= 3 && side >= 5) {
         const int A3Q = impl == 4 ? 1 : 2;
-        const int K = (D + 63) / 64, NXP = A3P * A3Q + 64 * K;
+        const int K = (D + 63) / 64, NPX = A3P * A3Q, NXP = NPX + 64 * K;
         const size_t shm3 = ((size_t)side * NXP + 256) * 8 + (size_t)(NXP + side) * 4;
-        const size_t nt = (size_t)N * side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
+        const size_t ntap = (size_t)side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
         hipStream_t st = smt_stream(stream);
+        static const bool verify = [] { const char *e = getenv("SMT_ASW_VERIFY"); return e && atoi(e) != 0; }();
+        const bool slots = impl == 6 && !verify;          // the check kernel compares a whole-image table
+        // impl 6: one slot of anchor weights per workgroup in flight (k_asw4); impl 3 / 4 / 5: the whole-image table
+        const int tpr = (W + NPX - 1) / NPX;
+        int nwg = tpr * H;
+        if (slots) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            const int per_cu = (K * A3Q <= 4) ? 2 : 1;   // what the kernel's launch bounds and its LDS tables admit
+            if (nwg > cus * per_cu) nwg = cus * per_cu;
+        }
+        const size_t tab_bytes = slots ? (size_t)nwg * NPX * ntap * 8 : (size_t)N * ntap * 8;
         double *w0 = nullptr;
         unsigned *a32 = nullptr;
-        if (shm3 <= 160 * 1024 && smt_scratch_alloc((void **)&w0, nt * 8, st) == hipSuccess) {
-            if (smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { smt_scratch_free(w0, st); return SMT_ERR_ALLOC; }
+        bool have = shm3 <= 160 * 1024 && smt_scratch_alloc((void **)&w0, tab_bytes, st) == hipSuccess;
+        if (have && smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { smt_scratch_free(w0, st); w0 = nullptr; have = false; }
+        if (have) {
             int rc = SMT_OK;                              // one exit path: the scratch is freed whatever happens
             const uint8_t *Ap = v == 0 ? Lp : Rp;
-            static const bool verify = [] { const char *e = getenv("SMT_ASW_VERIFY"); return e && atoi(e) != 0; }();
             unsigned long long *counts = nullptr;
             auto check_tables = [&](const char *when) {
                 // diagnostic only: a synchronising read-back of the comparison of both tables with their definition
                 unsigned long long h[6] = {0, 0, 0, 0, ~0ull, 0};
+                const size_t nt = (size_t)N * ntap;
                 if (hipMemcpyAsync(counts, h, sizeof h, hipMemcpyHostToDevice, st) != hipSuccess) return;
                 hipLaunchKernelGGL(k_asw_anchor_check, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32, counts);
                 if (hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
@@ -908,18 +1001,28 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
                         h[0] ? (long long)h[5] - 1 : -1ll, nt, h[3]);
             };
             if (verify && hipMalloc((void **)&counts, 64) != hipSuccess) counts = nullptr;
-            hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, Ap, H, W, wins, space, color, w0, a32);
-            if (counts) check_tables("after k_asw_anchor");
-            const dim3 grid((W + A3P * A3Q - 1) / (A3P * A3Q), H);
+            hipLaunchKernelGGL(k_asw_a32, dim3((unsigned)((na + 1023) / 1024 < 4096 ? (na + 1023) / 1024 : 4096)), dim3(256), 0, st, Ap, na, a32);
+            if (!slots) {
+                hipLaunchKernelGGL(k_asw_anchor, dim3((unsigned)(((size_t)N + 3) / 4)), dim3(256), 0, st, Ap, 0, H, W, wins, space, color, w0);
+                if (counts) check_tables("after k_asw_anchor");
+            }
+            const dim3 grid(tpr, H);
 #define SMT_ASW3(KK, QQ, SL)                                                                                 \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute((const void *)k_asw3<KK, QQ, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3); \
         if (e_ != hipSuccess) { g_smt_last_hip = (int)e_; rc = SMT_ERR_HIP; break; }                         \
-        hipLaunchKernelGGL((k_asw3<KK, QQ, SL>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost); \
+        hipLaunchKernelGGL((k_asw3<KK, QQ, SL>), grid, dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, color, w0, a32, T, v, disp, cost, 0); \
+    } while (0)
+#define SMT_ASW4(KK)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = hipFuncSetAttribute((const void *)k_asw4<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3); \
+        if (e_ != hipSuccess) { g_smt_last_hip = (int)e_; rc = SMT_ERR_HIP; break; }                         \
+        hipLaunchKernelGGL((k_asw4<KK, 2>), dim3((unsigned)nwg), dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, space, color, w0, a32, T, v, disp, cost); \
     } while (0)
 #define SMT_ASW3K(KK)                                                                                        \
     do {                                                                                                     \
-        if (impl == 5) SMT_ASW3(KK, 2, false);                                                               \
+        if (slots) SMT_ASW4(KK);                                                                             \
+        else if (impl == 5) SMT_ASW3(KK, 2, false);                                                          \
         else if (A3Q == 2) SMT_ASW3(KK, 2, true);                                                            \
         else SMT_ASW3(KK, 1, true);                                                                          \
     } while (0)
@@ -930,6 +1033,7 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
             default: SMT_ASW3K(4); break;
             }
 #undef SMT_ASW3K
+#undef SMT_ASW4
 #undef SMT_ASW3
             if (counts) { check_tables("after k_asw3"); (void)hipFree(counts); }
             smt_scratch_free(w0, st);

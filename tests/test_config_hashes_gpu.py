@@ -220,3 +220,58 @@ def test_a18_crossaggregator_full_size_vs_reference_build(smt, O, gold):
         check(O, rec, "cost", out)
         check(O, rec, "disp", smt.wta(out))
         ca.close()
+
+
+@pytest.mark.parametrize("D", [320, 257, 512])
+def test_disparity_range_above_256(smt, O, D):
+    """AD_Census::Initialize takes any `int dispRange` (AD-Census.h:322); the C ABI covers D <= SMT_MAX_DISPARITY = 512
+    on rows a1-a15 (beyond 256 a lane owns 5..8 hypotheses and the first-version kernels run).  AD-Census volumes + WTA,
+    arms + both aggregation orders + fused WTA, the four scanline passes + sum + WTA, the LR check and the batched
+    pipeline entry against the oracle, bit for bit, on a pair wider than D and on one narrower."""
+    for H, W, seed in ((12, D + 37, 5), (9, 150, 6)):
+        L, R = O.synth_pair(H, W, min(D, 64), seed)
+        Lf, Rf = T(L.astype(np.float32)), T(R.astype(np.float32))
+        adc = smt.AD_Census().Initialize(Lf, Rf, D, H, W, 10.0, 30.0)
+        dl, dr = torch.empty((H, W), device=DEV), torch.empty((H, W), device=DEV)
+        adc.ComputeBoth(dl, dr)
+        adc.status()
+        cl, cr = O.adcensus_view(L, R, D, 10.0, 30.0, 0), O.adcensus_view(L, R, D, 10.0, 30.0, 1)
+        assert np.array_equal(adc.GetPtrLeft().cpu().numpy().view(np.uint32), cl.view(np.uint32))
+        assert np.array_equal(adc.GetPtrRight().cpu().numpy().view(np.uint32), cr.view(np.uint32))
+        assert np.array_equal(dl.cpu().numpy(), O.wta(cl)) and np.array_equal(dr.cpu().numpy(), O.wta(cr))
+        assert np.array_equal(smt.wta(adc.GetPtrLeft()).cpu().numpy(), O.wta(cl))
+        ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+        ca.ComputeArmLengths(T(L))
+        arms = O.arms_all(L)
+        agg = torch.empty((H, W, D), device=DEV)
+        for order, fn in ((0, ca.AggregationVertical), (1, ca.costAggregationV5)):
+            fn(adc.GetPtrLeft(), agg, dl)
+            ref, _ = O.aggregate_rect(cl, arms, order)
+            assert np.array_equal(agg.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (D, order)
+            assert np.array_equal(dl.cpu().numpy(), O.wta(ref))
+        ca.AggregationVertical(adc.GetPtrLeft(), agg)
+        al, _ = O.aggregate_rect(cl, arms, 0)
+        so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, DEV)
+        out = torch.empty((H, W, D), device=DEV)
+        so.ScanLine(agg, Lf, out, dl)
+        ref = O.scanline(al, L.astype(np.float32), 10, 150)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), D
+        assert np.array_equal(dl.cpu().numpy(), O.wta(ref))
+        for o in (adc, ca, so):
+            o.close()
+        pipe = smt.Pipeline(H, W, D, DEV)
+        pdl, pdr, cls, counts = pipe.run(T(L), T(R))
+        from stereo_match_traditional_amd import SmtError
+        from stereo_match_traditional_amd._lib import SMT_ERR_REF_UB
+        try:
+            pipe.status()
+        except SmtError as e:
+            assert e.status == SMT_ERR_REF_UB, e
+        ar, _ = O.aggregate_rect(cr, O.arms_all(R), 0)
+        lr, c, no, nm = O.lrcheck(O.wta(ref), O.wta(ar), 2)
+        assert np.array_equal(pdl[0].cpu().numpy().view(np.uint32), lr.view(np.uint32))
+        assert np.array_equal(pdr[0].cpu().numpy(), O.wta(ar)) and np.array_equal(cls[0].cpu().numpy(), c)
+        pipe.close()
+    # and one past the limit is refused
+    with pytest.raises(SmtError):
+        smt.AD_Census().Initialize(Lf, Rf, 513, H, W, 10.0, 30.0)

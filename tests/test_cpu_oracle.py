@@ -112,7 +112,7 @@ def test_c_abi_argument_validation_without_gpu():
     L = lib()
     h = C.c_void_p()
     assert L.smt_adcensus_create(0, 10, 16, C.c_float(10), C.c_float(30), C.byref(h)) == -1
-    assert L.smt_adcensus_create(10, 10, 300, C.c_float(10), C.c_float(30), C.byref(h)) == -1     # D > 256
+    assert L.smt_adcensus_create(10, 10, 513, C.c_float(10), C.c_float(30), C.byref(h)) == -1     # D > SMT_MAX_DISPARITY
     assert L.smt_adcensus_create(10, 10, 16, C.c_float(0), C.c_float(30), C.byref(h)) == -1
     assert L.smt_adcensus_compute(None, None, None, 3, None, None) == -1
     assert L.smt_wta(None, 4, 4, 4, None, None) == -1

@@ -16,15 +16,16 @@ from oracle import oracle as O   # noqa: E402  (diagnostic tool: the oracle is t
 H, W, D, seed = 40, 90, 32, 5
 EXE = os.path.join(ROOT, "stereo_match_traditional_amd", "lib", "matchers_main")
 CONFIGS = [
-    ("default_pool_trimming__as_round2", {"SMT_SCRATCH_MODE": "default"}),
-    ("default_pool_trimming__verify", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_VERIFY": "1"}),
+    ("default_pool_trimming__as_round2", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "3"}),
+    ("default_pool_trimming__verify", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "3", "SMT_ASW_VERIFY": "1"}),
+    ("default_pool_trimming__per_workgroup_slots", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "6"}),
     ("default_pool_trimming__vector_loads", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "5"}),
-    ("default_pool_trimming__ncc_without_scratch", {"SMT_SCRATCH_MODE": "default", "SMT_NCC_IMPL": "1"}),
+    ("default_pool_trimming__ncc_without_scratch", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "3", "SMT_NCC_IMPL": "1"}),
     ("default_pool_trimming__asw_without_scratch", {"SMT_SCRATCH_MODE": "default", "SMT_ASW_IMPL": "1"}),
-    ("plain_hipMalloc", {"SMT_SCRATCH_MODE": "malloc"}),
-    ("plain_hipMalloc__verify", {"SMT_SCRATCH_MODE": "malloc", "SMT_ASW_VERIFY": "1"}),
-    ("library_pool_never_trimming", {"SMT_SCRATCH_MODE": "pool"}),
-    ("library_pool_never_trimming__verify", {"SMT_SCRATCH_MODE": "pool", "SMT_ASW_VERIFY": "1"}),
+    ("plain_hipMalloc", {"SMT_SCRATCH_MODE": "malloc", "SMT_ASW_IMPL": "3"}),
+    ("plain_hipMalloc__verify", {"SMT_SCRATCH_MODE": "malloc", "SMT_ASW_IMPL": "3", "SMT_ASW_VERIFY": "1"}),
+    ("library_pool_never_trimming", {"SMT_SCRATCH_MODE": "pool", "SMT_ASW_IMPL": "3"}),
+    ("library_pool_never_trimming__verify", {"SMT_SCRATCH_MODE": "pool", "SMT_ASW_IMPL": "3", "SMT_ASW_VERIFY": "1"}),
     ("arena_on_hipMalloc__shipped", {}),
     ("arena_on_hipMalloc__verify", {"SMT_ASW_VERIFY": "1"}),
 ]
