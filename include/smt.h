@@ -271,21 +271,24 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
                                              plane (or, order 2, were empty) since the previous status call */
-/* Test / tuning hook: which aggregation kernel runs.  7 = 2x8 pixels per wave, every tap of the
- * union of their rectangles loaded once and added under membership flags, 4-pixel groups without
- * a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
- * workgroup (8 x 8 pixels) walking their common bounding box in lock-step, one s_barrier per 64 positions
- * (default; also resets the strip width to 8), 6 = the same free-running (strip width 16), 4 = 6 with the
- * flags fetched per live group and pixel-by-pixel classification, 5 = 4 without the skip, 3 = 1x8 pixels without the skip,
- * 0 = four adjacent pixels per wave (mask switch), 1 = plain one-pixel-per-wave walk,
- * 2 = pipelined one-pixel-per-wave walk.  All produce identical bits. */
+/* Test / tuning hook: which aggregation kernel runs.  12 (default) = 4x4 pixels per wave, every tap of the union of
+ * their rectangles loaded once and added under membership flags (v_pk_fma_f32, flag pairs in SGPRs), tile rows
+ * without a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
+ * workgroup (8 x 8 pixels) walking their common bounding box in lock-step, one s_barrier per 64 positions;
+ * 7 = the same with 2x8 tiles; 6 = 7 free-running (strip width 16); 4 = 6 with the flags fetched per live group and
+ * pixel-by-pixel classification; 5 = 4 without the skip; 3 = 1x8 pixels without the skip; 8, 9, 10, 11, 13 = the
+ * flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1_16b_f32 with A = membership flags: every group; live groups
+ * only; one A register per tap through the instruction's broadcast field; upper tile row on the matrix pipe and lower
+ * row on the vector pipe; live groups with 4x4 tiles); 0 = four adjacent pixels per wave, 16-way switch on the mask;
+ * 1 = plain one-pixel-per-wave walk (the only form for volumes >= 4 GiB, D > 256 and order 2); 2 = pipelined walk.
+ * Every variant produces the same bits. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps (all variants but 1;
  * variants 3 and 4 round it to 8, 16 or a multiple of 32). */
 int smt_crossarm_set_strip_width(smt_crossarm *h, int width);
 /* Tuning hook: aggregation waves per SIMD (3, 4 or 5, enforced through an LDS claim per workgroup; 0 = whatever the
- * register count allows, i.e. 6).  Default 4: the aggregation is no slower than at 6, and 192 of a SIMD's 512
- * VGPRs stay free for kernels of other streams (the scanline passes of smt_pipeline_run_batch run beside it).
+ * register count allows, i.e. 6: the default).  Limiting it leaves VGPRs for kernels of other streams, which on this
+ * path buys nothing (the scanline passes then run beside the aggregation and both slow down).
  * SMT_AGG_WAVES in the environment overrides the default for every handle. */
 int smt_crossarm_set_occupancy(smt_crossarm *h, int waves_per_simd);
 /* Tuning hook (variants 3-5): 0 = column strips interleaved over the 8 XCDs, 1 = every XCD owns one
@@ -514,8 +517,9 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
             void *stream);
 /* Scratch device memory of smt_asw / smt_ncc comes from an arena the library owns (csrc/scratch.hip: hipMalloc'ed
  * blocks cached per device and handed out stream-ordered on the caller's stream).  The arena keeps what it has grown
- * to -- the anchor-weight slots of an smt_asw call (one per workgroup in flight: 512 x 32 x (2*winSize+3)^2 x 8
- * bytes, 160 MB at 35 x 35, whatever the image size), 24*H*W bytes after an smt_ncc -- until the process ends or the host asks
+ * to -- the anchor weights of an smt_asw call (H*W*(2*winSize+3)^2*8 bytes while that is under 6 GiB, beyond it one
+ * slot per workgroup in flight: 160 MB at 35 x 35 whatever the image size), 24*H*W bytes after an smt_ncc -- until the
+ * process ends or the host asks
  * for it back: smt_scratch_trim synchronises the current device and returns every idle block beyond `keep_bytes` to
  * the driver (hipFree); smt_scratch_info reports what the arena holds / has handed out.
  * Why not hipMallocAsync: on ROCm 7.2 a stream-ordered pool that trims and grows again hands out a block that is
@@ -524,10 +528,11 @@ int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winSi
  * device's default pool (the failing configuration) / plain hipMalloc per call. */
 int smt_scratch_trim(size_t keep_bytes);
 int smt_scratch_info(size_t *reserved_bytes, size_t *used_bytes);
-/* Test hook (process-wide): which ASW formulation runs.  6 (default) = per-row other-image weight tables in LDS and
- * the anchor weights in one scratch slot per workgroup in flight, rebuilt by the workgroup for every tile it takes
- * (k_asw4; scratch independent of the image size); 3 = the same tap loop over a whole-image anchor table written by
- * a table kernel first (H*W*(2*winSize+3)^2*8 bytes of scratch: 5 GB at 960x540, 35x35), two pixels per wave;
+/* Test hook (process-wide): which ASW formulation runs.  0 (default) = 3 while the whole-image anchor table stays
+ * under 6 GiB (SMT_ASW_TABLE_MAX_MB), 6 beyond.  3 = per-row other-image weight tables in LDS, anchor weights from a
+ * whole-image table written by a table kernel first (H*W*(2*winSize+3)^2*8 bytes of scratch: 5 GB at 960x540, 35x35),
+ * two pixels per wave; 6 = the same tap loop with the anchor weights in one scratch slot per workgroup in flight, rebuilt
+ * by the workgroup for every tile it takes (k_asw4: 160 MB at 35x35 whatever the image size, 7 % slower at config 4);
  * 4 = 3 with one pixel per wave; 5 = 3 with the anchor operands read by vector loads instead of through the scalar
  * cache; 1 = the first formulation (everything recomputed per tap; also the fallback when the scratch cannot be had).
  * All produce identical bits. */

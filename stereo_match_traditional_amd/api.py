@@ -342,10 +342,9 @@ class CrossArmAggregation:
         wta(AggredCostVolume, disp)
 
     def set_variant(self, variant):
-        """7 = 2x8 pixels per wave sharing union taps, flags prefetched, waves of a workgroup in lock-step
-        (default), 6 = the same free-running, 4 = flags per live group,
-        5 = no group skip, 3 = 1x8,
-        0 = four pixels per wave, 1 plain walk, 2 pipelined walk."""
+        """12 = 4x4 pixels per wave sharing union taps, lock-step workgroups (default), 7 = the same with 2x8 tiles,
+        6 = free-running, 4 / 5 / 3 = earlier shared-tap forms, 8-11, 13 = flagged accumulate on the matrix pipe,
+        0 = four pixels per wave, 1 plain walk, 2 pipelined walk (include/smt.h)."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
 
     def set_arm_walk(self, on=True):
@@ -750,7 +749,7 @@ def asw_batch(leftGrays, rightGrays, winSize, dispRange, space, color, T, view=V
 
 
 def asw_set_impl(impl):
-    """6 = per-workgroup anchor slots (default), 3 / 4 / 5 = whole-image anchor table variants, 1 = first formulation (test hook)."""
+    """0 = automatic (default: 3 up to a 6 GiB table, 6 beyond), 3 / 4 / 5 = whole-image anchor table variants, 6 = per-workgroup anchor slots, 1 = first formulation (test hook)."""
     check(lib().smt_asw_set_impl(int(impl)), "smt_asw_set_impl")
 
 

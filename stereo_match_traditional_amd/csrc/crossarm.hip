@@ -639,14 +639,18 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // q = r*8 + c).  Lane q keeps pixel q's rectangle (box coordinates relative to the block's top-left
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
-template <int C, int ORDER, bool FULL, int QR, int SKIP>
+template <int C, int ORDER, bool FULL, int QR, int SKIP, int TWS = 3>
 __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
                                                         int *ub_flag, int SW, const float *__restrict__ member, int sweep)
 {
-    constexpr int QC = 8, NPIX = QC * QR;
+    // tile geometry: pixel q of the wave sits at row q >> TWS, column q & (QC - 1) of a TH x QC tile.  TWS = 3: QR x 8
+    // (q's bit position in the membership mask and its place in the tile coincide); TWS = 2 with QR = 2: 4 x 4 pixels --
+    // the most compact 16-pixel tile, 7-8 % fewer union taps on the benchmark pair (233 against 252 per tile) -- with
+    // mask bits, flag rows and skip groups unchanged (a group of four = one row of the tile).
+    constexpr int NPIX = 8 * QR, QC = 1 << TWS, TH = NPIX >> TWS;
     constexpr int G = (QR == 1) ? 8 : 4;                 // union taps loaded per group
     constexpr int BIAS = 16384;
     // SKIP == 3 ("lock-step"): SKIP == 2 plus one s_barrier per batch of 64 box positions, with all four waves
@@ -687,14 +691,14 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int wx = min(NT / 64, SW / QC), wy = (NT / 64) / wx;
         const int gpr = SW / (QC * wx);
-        const int nband = (H + wy * QR - 1) / (wy * QR);
+        const int nband = (H + wy * TH - 1) / (wy * TH);
         int row, col;
         if (sweep == 0) {
             // strips interleaved over the XCDs: XCD x sweeps strips x, x+8, ... top to bottom
             const int gps = gpr * nband;
             const int strip = xcd + 8 * (slot / gps);
             const int g = slot % gps;
-            row = ((g / gpr) * wy + wv / wx) * QR;
+            row = ((g / gpr) * wy + wv / wx) * TH;
             col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
         } else {
             // XCD x owns the x-th contiguous band of rows and sweeps it strip by strip: the column halo
@@ -703,11 +707,11 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
             const int gps = gpr * nbx;
             const int strip = slot / gps;
             const int g = slot % gps;
-            row = ((xcd * nbx + g / gpr) * wy + wv / wx) * QR;
+            row = ((xcd * nbx + g / gpr) * wy + wv / wx) * TH;
             col = strip * SW + ((g % gpr) * wx + (wv % wx)) * QC;
         }
         if (SYNC) {
-            const int roff = (wv / wx) * QR, coff = (wv % wx) * QC;
+            const int roff = (wv / wx) * TH, coff = (wv % wx) * QC;
             ooff = (ORDER == 0) ? coff : roff;
             ioff = (ORDER == 0) ? roff : coff;
         }
@@ -717,7 +721,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
             ncol = 0; nrow = 0;
         } else {
             ncol = min(QC, W - col);
-            nrow = min(QR, H - row);
+            nrow = min(TH, H - row);
         }
         p0 = row * W + col;
     }
@@ -726,7 +730,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     int my_oa = 1, my_ob = 0, my_ia = 1, my_ib = 0;
     bool my_ub = false;
     {
-        const int r = lane >> 3, c = lane & 7;
+        const int r = lane >> TWS, c = lane & (QC - 1);
         if (lane < NPIX && r < nrow && c < ncol) {
             const int p = p0 + r * W + c;
             const int Ll = armL[p], Rr = armR[p], up = armT[p], dn = armB[p];
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     int omin = INT_MAX, omax = INT_MIN, imin = INT_MAX, imax = INT_MIN;
 #pragma unroll
     for (int q = 0; q < NPIX; q++) {
-        if ((q >> 3) < nrow && (q & 7) < ncol) {
+        if ((q >> TWS) < nrow && (q & (QC - 1)) < ncol) {
             omin = min(omin, __builtin_amdgcn_readlane(my_oa, q)); omax = max(omax, __builtin_amdgcn_readlane(my_ob, q));
             imin = min(imin, __builtin_amdgcn_readlane(my_ia, q)); imax = max(imax, __builtin_amdgcn_readlane(my_ib, q));
         }
@@ -1032,7 +1036,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     auto finish = [&](int q, const float (&a)[C]) {
         const unsigned bo = (unsigned)__builtin_amdgcn_readlane((int)pk_o, q), bi = (unsigned)__builtin_amdgcn_readlane((int)pk_i, q);
         const float fc = (float)(((int)(bo >> 16) - (int)(bo & 0xffffu) + 1) * ((int)(bi >> 16) - (int)(bi & 0xffffu) + 1));
-        const int p = p0 + (q >> 3) * W + (q & 7);
+        const int p = p0 + (q >> TWS) * W + (q & (QC - 1));
         float *dst = vout + (size_t)p * D + dl;
         float mean[C];
 #pragma unroll
@@ -1052,7 +1056,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     unsigned redo = 0;
 #pragma unroll
     for (int q = 0; q < NPIX; q++) {
-        if ((q >> 3) >= nrow || (q & 7) >= ncol) continue;
+        if ((q >> TWS) >= nrow || (q & (QC - 1)) >= ncol) continue;
         float a[C];
         bool bad = ub;
 #pragma unroll
@@ -1251,11 +1255,11 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
-    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 7;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 12;
     {
-        // default: 4 workgroups (= 4 waves per SIMD) per CU, see smt_crossarm_set_occupancy; SMT_AGG_WAVES overrides
+        // default: no limit (6 waves per SIMD from the register count), see smt_crossarm_set_occupancy; SMT_AGG_WAVES overrides
         static const int env_waves = [] { const char *e = getenv("SMT_AGG_WAVES"); return e ? atoi(e) : -1; }();
-        const int waves = env_waves >= 0 ? env_waves : 4;
+        const int waves = env_waves >= 0 ? env_waves : 0;
         h->occ_lds = (waves >= 3 && waves <= 5) ? (160 * 1024 / waves - 512) & ~255 : 0;   // <= 64 KB: no attribute needed
     }
     if (p) h->P = *p; else smt_crossarm_default_params(&h->P);
@@ -1430,23 +1434,25 @@ static void launch_agg_quad(smt_crossarm *h, const float *vin, float *vout, floa
 #undef SMT_AGGQ
 }
 
-template <int ORDER, int QR, int SKIP>
+template <int ORDER, int QR, int SKIP, int TWS = 3>
 static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, float *disp)
 {
-    // strip width 8 / 16 / multiple of 32: the 4 waves of a workgroup sit 1x4, 2x2 or 4x1
+    // strip width 8 / 16 / multiple of 32: the 4 waves of a workgroup sit 1x4, 2x2 or 4x1 (tiles 8 wide; 4-wide
+    // tiles: 2x2 at strip width 8, 4x1 from 16 on)
+    constexpr int TW = 1 << TWS, TH = (8 * QR) >> TWS;
     int SW = h->strip_w8;
     SW = SW <= 8 ? 8 : SW <= 16 ? 16 : ((SW + 31) / 32) * 32;
-    const int wx = SW / 8 < 4 ? SW / 8 : 4, wy = 4 / wx;
+    const int wx = SW / TW < 4 ? SW / TW : 4, wy = 4 / wx;
     const int nstrips = (h->W + SW - 1) / SW;
     const int per_xcd = (nstrips + 7) / 8;
-    const int nband = (h->H + wy * QR - 1) / (wy * QR);
-    dim3 grid(h->sweep == 0 ? (unsigned)(8 * per_xcd * (SW / (8 * wx)) * nband)
-                            : (unsigned)(8 * nstrips * (SW / (8 * wx)) * ((nband + 7) / 8)));
+    const int nband = (h->H + wy * TH - 1) / (wy * TH);
+    dim3 grid(h->sweep == 0 ? (unsigned)(8 * per_xcd * (SW / (TW * wx)) * nband)
+                            : (unsigned)(8 * nstrips * (SW / (TW * wx)) * ((nband + 7) / 8)));
     const int C = (h->D + 63) / 64;
     const bool full = (h->D == 64 * C);
     int *ub = h->flip + 4;
 #define SMT_AGGM(CC, FF)                                                                                  \
-    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP>), grid, dim3(NT), (size_t)h->occ_lds, h->stream, vin, vout, h->H, h->W, \
+    hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP, TWS>), grid, dim3(NT), (size_t)h->occ_lds, h->stream, vin, vout, h->H, h->W, \
                        h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member, h->sweep)
     switch (C * 2 + (full ? 1 : 0)) {
     case 2: SMT_AGGM(1, false); break;
@@ -1545,13 +1551,15 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     if (!h || !vin || !vout || vin == vout || order < 0 || order > 2) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     if (!h->have_arms) return SMT_ERR_STATE;
-    // variant: 7 = 2x8 pixels per wave sharing the taps of the union of their rectangles, membership flags,
-    // groups of 4 pixels without a member skipped, flag rows prefetched, per-axis membership tables, the
-    // four waves of a workgroup in lock-step (default); 6 = the same free-running; 4 = 6 with flags per live
-    // group and pixel-by-pixel classification; 5 = 4 without the skip; 3 = 1x8 pixels, no skip; 0 = 4
-    // adjacent pixels per wave with a 16-way switch on the membership mask; 1 = plain one-pixel-per-wave
-    // walk (also the form used for volumes >= 4 GiB and for order 2); 2 = pipelined one-pixel-per-wave
-    // walk.  All but 1 address taps with 32-bit byte offsets.
+    // variant: 12 = 4x4 pixels per wave sharing the taps of the union of their rectangles, membership flags,
+    // groups of 4 pixels (= tile rows) without a member skipped, flag rows prefetched, per-axis membership tables, the
+    // four waves of a workgroup (8 x 8 pixels) in lock-step (default); 7 = the same with 2x8 tiles (round 2's default);
+    // 6 = 7 free-running; 4 = 6 with flags per live group and pixel-by-pixel classification; 5 = 4 without the skip;
+    // 3 = 1x8 pixels, no skip; 8 / 9 / 10 = 7 with the flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1: every
+    // group / live groups only / one A register per tap through the broadcast field); 11 = upper tile row on the matrix
+    // pipe, lower row on the vector pipe; 13 = 9 with 4x4 tiles; 0 = 4 adjacent pixels per wave with a 16-way switch on
+    // the membership mask; 1 = plain one-pixel-per-wave walk (also the form used for volumes >= 4 GiB, for D > 256 and
+    // for order 2); 2 = pipelined one-pixel-per-wave walk.  All but 1 address taps with 32-bit byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
     if (h->D > 256) variant = 1;                          // 5..8 hypotheses per lane: the plain walk only
@@ -1567,6 +1575,8 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 9) { if (order == 0) launch_agg_multi<0, 2, 5>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5>(h, vin, vout, disp); }
     else if (variant == 10) { if (order == 0) launch_agg_multi<0, 2, 6>(h, vin, vout, disp); else launch_agg_multi<1, 2, 6>(h, vin, vout, disp); }
     else if (variant == 11) { if (order == 0) launch_agg_multi<0, 2, 7>(h, vin, vout, disp); else launch_agg_multi<1, 2, 7>(h, vin, vout, disp); }
+    else if (variant == 12) { if (order == 0) launch_agg_multi<0, 2, 3, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3, 2>(h, vin, vout, disp); }
+    else if (variant == 13) { if (order == 0) launch_agg_multi<0, 2, 5, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5, 2>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1574,7 +1584,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 11) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 13) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->variant = variant;
     // the lock-step kernel wants its four waves stacked vertically (8 columns x 8 rows per workgroup: the
@@ -1598,12 +1608,12 @@ SMT_API int smt_crossarm_set_arm_walk(smt_crossarm *h, int on)
     return SMT_OK;
 }
 
-// Aggregation workgroups per CU (= waves per SIMD: a workgroup is four waves, one per SIMD).  The kernel needs 80
-// VGPRs; left alone it runs 6 waves per SIMD = 480 of the 512 VGPRs, and a kernel on another stream (the scanline
-// passes want 96 per wave) never finds room until the aggregation's grid is exhausted -- the two then run one after
-// the other whatever the streams say.  The aggregation itself is flat between 4 and 6 waves per SIMD,
-// so by default every workgroup also claims 1/4 of the CU's LDS it does not use: 4 waves per SIMD, 192 VGPRs per
-// SIMD left for whatever else is running.  waves = 0 removes the limit (6 per SIMD, from the VGPR count).
+// Aggregation workgroups per CU (= waves per SIMD: a workgroup is four waves, one per SIMD), enforced through an LDS
+// claim the kernel does not use.  The kernel needs 80 VGPRs; left alone it runs 6 waves per SIMD = 480 of the 512
+// VGPRs, so a kernel on another stream finds no room until the aggregation's grid is exhausted.  Round 3 measured what
+// making room buys: nothing -- scanline passes resident beside the aggregation slow down with it,
+// both wait on the same memory system -- while the aggregation alone loses 15 % at 4 or 5 waves per SIMD.  The default
+// is therefore no limit; the knob stays for experiments.
 SMT_API int smt_crossarm_set_occupancy(smt_crossarm *h, int waves_per_simd)
 {
     if (!h || !(waves_per_simd == 0 || (waves_per_simd >= 3 && waves_per_simd <= 5))) return SMT_ERR_ARG;

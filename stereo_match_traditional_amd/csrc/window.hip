@@ -660,9 +660,23 @@ __device__ __forceinline__ void asw3_tile(const uint8_t *__restrict__ Lp, const 
     double *s_T = (double *)smem;                          // [NXP][side]
     double *s_color = s_T + (size_t)side * NXP;            // [256], filled by the caller
     float *s_P = (float *)(s_color + 256);                 // [NXP + side]: the other image's current window row as floats
+    // OWN only: squared spatial mask [side^2] (filled by the caller) and the tile's anchor window [side][SA] bytes
+    double *s_sp2 = (double *)(s_P + ((NXP + side + 1) & ~1));
+    uint8_t *s_A = (uint8_t *)(s_sp2 + (OWN ? side * side : 0));
+    const int SA = NPX + side - 1;
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (OWN) {
+        // anchor window of the tile: rows io .. io + side - 1, padded columns jo0 .. jo0 + NPX + side - 2 (clamped)
+        const uint8_t *Aimg = (view == 0 ? Lp : Rp) + (size_t)io * Wp;
+        for (int e = threadIdx.x; e < side * SA; e += A3P * 64) {
+            const int r = e / SA, xx = e - r * SA;
+            const int x = jo0 + xx;
+            s_A[e] = Aimg[(size_t)r * Wp + (x < Wp ? x : Wp - 1)];
+        }
+        __syncthreads();
+    }
     // the other image and the first window position the workgroup can touch:
     //   view 0: xs = jo - dd in [jo0 - (D-1), jo0 + NPX-1];   view 1: xs = jo + dd in [jo0, jo0 + NPX-1 + D-1]
     const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
@@ -687,18 +701,19 @@ __device__ __forceinline__ void asw3_tile(const uint8_t *__restrict__ Lp, const 
         double *wtab = OWN ? w0 + ((size_t)wv * A3Q + q) * side * side : w0 + ((size_t)(io - i0) * W + jc) * side * side;
         wrow[q] = (cdouble_p)wtab;
         if (OWN) {
-            // this pixel's anchor weights: color[|A(q) - A(centre)|] * space(q)^2, the two products of k_asw in its order
-            const uint8_t *A = (view == 0 ? Lp : Rp) + (size_t)io * Wp + jc;
-            const int ca = A[wins * Wp + wins];
+            // this pixel's anchor weights: color[|A(q) - A(centre)|] * space(q)^2, the two products of k_asw in its
+            // order, from the tile's anchor window and the squared spatial mask staged in LDS by the caller
+            const int xx0 = jc - jo0;
+            const int ca = s_A[wins * SA + xx0 + wins];
             const int ntap = side * side;
             const float rs = 1.0f / (float)side;
+#pragma unroll 4
             for (int t = lane; t < ntap; t += 64) {
                 int r = (int)((float)t * rs);              // t / side, corrected below
                 int c = t - r * side;
                 if (c < 0) { r--; c += side; }
                 if (c >= side) { r++; c -= side; }
-                const double sp = space[t];
-                wtab[t] = s_color[abs((int)A[r * Wp + c] - ca)] * (sp * sp);
+                wtab[t] = s_color[abs((int)s_A[r * SA + xx0 + c] - ca)] * s_sp2[t];
             }
         }
         arow[q] = (cunsigned_p)(a32 + (size_t)io * Wp + jc);
@@ -832,10 +847,19 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw4(const
     constexpr int NPX = A3P * A3Q, NXP = NPX + 64 * K;
     const int side = 2 * wins + 1;
     double *s_color = (double *)smem + (size_t)side * NXP;
+    float *s_P = (float *)(s_color + 256);
+    double *s_sp2 = (double *)(s_P + ((NXP + side + 1) & ~1));
     for (int e = threadIdx.x; e < 256; e += A3P * 64) s_color[e] = color[e];
-    __syncthreads();                                       // the anchor phase of the first tile reads s_color
+    for (int e = threadIdx.x; e < side * side; e += A3P * 64) { const double sp = space[e]; s_sp2[e] = sp * sp; }
+    // (the anchor phase of a tile reads both after the barrier that follows its window staging)
     const int tpr = (W + NPX - 1) / NPX, ntiles = tpr * H;
     double *slot = slots + (size_t)blockIdx.x * NPX * side * side;
+#ifdef SMT_ASW4_STAGGER
+    // experiment: the second workgroup of every CU starts about half a tile late, so that the barrier-separated
+    // table-building phases of the two do not coincide for the whole launch
+    if (blockIdx.x >= gridDim.x / 2)
+        for (int k = 0; k < SMT_ASW4_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asw3_tile<K, A3Q, true, true>(Lp, Rp, H, W, D, wins, space, slot, a32, T, view, disp, cost_out, 0, tile / tpr,
                                       (tile % tpr) * NPX, smem);
@@ -846,10 +870,13 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw4(const
 
 }  // namespace
 
-static int g_asw_impl = 6;   // 6: k_asw4, anchor weights in per-workgroup slots (default); 3: k_asw_anchor + k_asw3 over a whole-image table, two pixels per wave; 4: one pixel per wave; 5: as 3 with vector loads of the anchor operands; 1: k_asw (first formulation)
+// 0 (default): 3 while the whole-image anchor table stays under kAswTableMax bytes, 6 beyond; 3: k_asw_anchor + k_asw3 over
+// a whole-image table, two pixels per wave; 6: k_asw4, anchor weights in per-workgroup slots; 4: 3 with one pixel per wave;
+// 5: 3 with vector loads of the anchor operands; 1: k_asw (first formulation)
+static int g_asw_impl = 0;
 SMT_API int smt_asw_set_impl(int impl)
 {
-    if (impl != 1 && impl != 3 && impl != 4 && impl != 5 && impl != 6) return SMT_ERR_ARG;
+    if (impl != 0 && impl != 1 && impl != 3 && impl != 4 && impl != 5 && impl != 6) return SMT_ERR_ARG;
     g_asw_impl = impl;
     return SMT_OK;
 }
@@ -962,12 +989,21 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     const int N = H * W;
     const int v = view == SMT_VIEW_LEFT ? 0 : 1;
     static const int env_impl = [] { const char *e = getenv("SMT_ASW_IMPL"); return e ? atoi(e) : 0; }();   // debugging aid: overrides smt_asw_set_impl
-    const int impl = env_impl ? env_impl : g_asw_impl;
+    int impl = env_impl ? env_impl : g_asw_impl;
+    if (impl == 0) {
+        // the table kernels are 7 % faster at config 4 (17.6 against 18.9 ms), the slots need 160 MB whatever the image:
+        // table up to SMT_ASW_TABLE_MAX_MB (default 6 144: config 4 takes 5 085), slots beyond (1080p at 35x35: 22.7 GB)
+        static const size_t kAswTableMax = [] { const char *e = getenv("SMT_ASW_TABLE_MAX_MB"); return (size_t)(e ? atoi(e) : 6144) << 20; }();
+        impl = (size_t)N * side * side * 8 <= kAswTableMax ? 3 : 6;
+    }
     if (impl >= 3 && side >= 5) {
         const int A3Q = impl == 4 ? 1 : 2;
         const int K = (D + 63) / 64, NPX = A3P * A3Q, NXP = NPX + 64 * K;
         const size_t shm3 = ((size_t)side * NXP + 256) * 8 + (size_t)(NXP + side) * 4;
         const size_t ntap = (size_t)side * side, na = (size_t)(H + 2 * wins) * (W + 2 * wins);
+        // k_asw4 adds the squared spatial mask and the tile's anchor window to the LDS image of k_asw3
+        const size_t shm4 = ((size_t)side * NXP + 256) * 8 + (size_t)((NXP + side + 1) & ~1) * 4 + ntap * 8 +
+                            (((size_t)side * (NPX + side - 1) + 15) & ~(size_t)15);
         hipStream_t st = smt_stream(stream);
         static const bool verify = [] { const char *e = getenv("SMT_ASW_VERIFY"); return e && atoi(e) != 0; }();
         const bool slots = impl == 6 && !verify;          // the check kernel compares a whole-image table
@@ -983,7 +1019,7 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         const size_t tab_bytes = slots ? (size_t)nwg * NPX * ntap * 8 : (size_t)N * ntap * 8;
         double *w0 = nullptr;
         unsigned *a32 = nullptr;
-        bool have = shm3 <= 160 * 1024 && smt_scratch_alloc((void **)&w0, tab_bytes, st) == hipSuccess;
+        bool have = (slots ? shm4 : shm3) <= 160 * 1024 && smt_scratch_alloc((void **)&w0, tab_bytes, st) == hipSuccess;
         if (have && smt_scratch_alloc((void **)&a32, na * 4, st) != hipSuccess) { smt_scratch_free(w0, st); w0 = nullptr; have = false; }
         if (have) {
             int rc = SMT_OK;                              // one exit path: the scratch is freed whatever happens
@@ -1015,9 +1051,9 @@ SMT_API int smt_asw(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
     } while (0)
 #define SMT_ASW4(KK)                                                                                         \
     do {                                                                                                     \
-        hipError_t e_ = hipFuncSetAttribute((const void *)k_asw4<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm3); \
+        hipError_t e_ = hipFuncSetAttribute((const void *)k_asw4<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm4); \
         if (e_ != hipSuccess) { g_smt_last_hip = (int)e_; rc = SMT_ERR_HIP; break; }                         \
-        hipLaunchKernelGGL((k_asw4<KK, 2>), dim3((unsigned)nwg), dim3(A3P * 64), shm3, st, Lp, Rp, H, W, D, wins, space, color, w0, a32, T, v, disp, cost); \
+        hipLaunchKernelGGL((k_asw4<KK, 2>), dim3((unsigned)nwg), dim3(A3P * 64), shm4, st, Lp, Rp, H, W, D, wins, space, color, w0, a32, T, v, disp, cost); \
     } while (0)
 #define SMT_ASW3K(KK)                                                                                        \
     do {                                                                                                     \

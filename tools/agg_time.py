@@ -24,17 +24,21 @@ variants = [int(v) for v in os.environ.get("AGG_VARIANTS", "7").split(",")]
 for name, img, vol in (("left", Lu, adc.GetPtrLeft()), ("right", Ru, adc.GetPtrRight())):
     ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
     ca.ComputeArmLengths(img)
-    for v in variants:
-        ca.set_variant(v)
-        for _ in range(2):
-            ca.AggregationVertical(vol, out)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(5):
-            ca.AggregationVertical(vol, out)
-        b.record()
-        torch.cuda.synchronize()
-        res[f"{name}_v{v}_ms"] = round(a.elapsed_time(b) / 5, 4)
+    # interleaved rounds: the first measurement of a process runs ~8 % slower than later ones whatever the variant
+    # (clock / memory state), so every variant is timed in every round and the rounds are reported one by one
+    rounds = int(os.environ.get("AGG_ROUNDS", "3"))
+    for rnd in range(rounds):
+        for v in variants:
+            ca.set_variant(v)
+            for _ in range(2):
+                ca.AggregationVertical(vol, out)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                ca.AggregationVertical(vol, out)
+            b.record()
+            torch.cuda.synchronize()
+            res.setdefault(f"{name}_v{v}_ms", []).append(round(a.elapsed_time(b) / 5, 4))
     ca.close()
 print(json.dumps(res), flush=True)

@@ -13,6 +13,20 @@ root = sys.argv[1]
 V = 1080 * 1920 * 192
 
 
+def short_name(k):
+    """'void (anonymous namespace)::k_scan<3, 2, 3, true>((anonymous namespace)::ScanArgs)' -> 'k_scan<3, 2, 3, true>'"""
+    k = k.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(k):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return k[:i]
+    return k
+
+
 def per_kernel(pattern, counters):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(pattern, recursive=True):
@@ -29,7 +43,7 @@ alg = {"k_scan_lr": 16, "k_scan<3, 2": 16, "k_scan<3, 3": 12}
 for k in sorted(set(f) | set(w)):
     if "k_scan" not in k:
         continue
-    short = k.split("(")[0].replace("void (anonymous namespace)::", "")
+    short = short_name(k)
     fv, wv = f.get(k, {}).get("FETCH_SIZE", []), w.get(k, {}).get("WRITE_SIZE", [])
     fetch = 2.0 * 1024 * sum(fv) / max(1, len(fv))
     write = 1024.0 * sum(wv) / max(1, len(wv))
@@ -45,8 +59,9 @@ for D in (64, 200):
             continue
         m = {a: sum(b) / len(b) for a, b in c.items()}
         out["ncc_450x375_w21"][f"D={D}"] = {
-            "kernel": k.split("(")[0].replace("void (anonymous namespace)::", ""), **{a: round(b) for a, b in m.items()},
+            "kernel": short_name(k), **{a: round(b) for a, b in m.items()},
             "lds_bytes_if_all_b32": round(m.get("SQ_INSTS_LDS", 0) * 256),
+            "lds_array_busy": round(m.get("SQ_LDS_IDX_ACTIVE", 0) / 256.0 / (m.get("GRBM_GUI_ACTIVE", 1) / 8.0), 3),
             "note": "SQ_INSTS_LDS wave-instructions x 256 B (64 lanes x 4 B): the kernel's LDS traffic is ds_read_b32; "
                     "GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
 print(json.dumps(out, indent=1))
