@@ -276,12 +276,12 @@ int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: repo
  * without a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
  * workgroup (8 x 8 pixels) walking their common bounding box in lock-step, one s_barrier per 64 positions;
  * 7 = the same with 2x8 tiles; 6 = 7 free-running (strip width 16); 4 = 6 with the flags fetched per live group and
- * pixel-by-pixel classification; 5 = 4 without the skip; 3 = 1x8 pixels without the skip; 8, 9, 10, 11, 13 = the
- * flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1_16b_f32 with A = membership flags: every group; live groups
- * only; one A register per tap through the instruction's broadcast field; upper tile row on the matrix pipe and lower
- * row on the vector pipe; live groups with 4x4 tiles); 0 = four adjacent pixels per wave, 16-way switch on the mask;
- * 1 = plain one-pixel-per-wave walk (the only form for volumes >= 4 GiB, D > 256 and order 2); 2 = pipelined walk.
- * Every variant produces the same bits. */
+ * pixel-by-pixel classification; 5 = 4 without the skip; 3 = 1x8 pixels without the skip; 8, 9, 11 = the flagged
+ * accumulate on the matrix pipe (v_mfma_f32_4x4x1_16b_f32 with A = membership flags: every group / live groups only /
+ * live groups with 4x4 tiles); 10 = four taps per v_mfma_f32_16x16x4_f32 (4x4 tiles, free-running, D a multiple of
+ * 64, else 12 runs); 0 = four adjacent pixels per wave, 16-way switch on the mask; 1 = plain one-pixel-per-wave walk
+ * (the only form for volumes >= 4 GiB, D > 256 and order 2); 2 = pipelined walk.  Every variant produces the same bits;
+ * the matrix-pipe forms are measured equal to or slower than the default. */
 int smt_crossarm_set_variant(smt_crossarm *h, int variant);
 /* Tuning hook: width (multiple of 4) of the column strips each XCD sweeps (all variants but 1;
  * variants 3 and 4 round it to 8, 16 or a multiple of 32). */

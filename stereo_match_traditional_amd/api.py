@@ -343,7 +343,7 @@ class CrossArmAggregation:
 
     def set_variant(self, variant):
         """12 = 4x4 pixels per wave sharing union taps, lock-step workgroups (default), 7 = the same with 2x8 tiles,
-        6 = free-running, 4 / 5 / 3 = earlier shared-tap forms, 8-11, 13 = flagged accumulate on the matrix pipe,
+        6 = free-running, 4 / 5 / 3 = earlier shared-tap forms, 8-11 = flagged accumulate on the matrix pipe,
         0 = four pixels per wave, 1 plain walk, 2 pipelined walk (include/smt.h)."""
         check(lib().smt_crossarm_set_variant(self._h, int(variant)), "smt_crossarm_set_variant")
 

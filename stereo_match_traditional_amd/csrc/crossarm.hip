@@ -640,7 +640,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
 template <int C, int ORDER, bool FULL, int QR, int SKIP, int TWS = 3>
-__global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3) : SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
@@ -664,21 +664,22 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     // carries its hypotheses as before), accumulator register i of lane l becomes acc_i[l] + flag_i * x[l] -- the same
     // one-rounding fma per element as v_pk_fma_f32 (tools/mfma_flag_probe.hip: bit-identical to the v_fma chain and
     // to plain adds on 4 096 taps of normal, denormal, negative and huge values), in the accumulator layout the
-    // kernel already has, at the same 256 FMA per 8 cycles per SIMD -- but on the other pipe, in 12 instructions per
-    // tap instead of 2.4 x (6 v_pk_fma + v_mov), with no flag rows to fetch through the scalar cache (the flags are
-    // two VALU operations on the membership mask) and, for SKIP == 4, no branch in the tap loop at all.
-    // 5 = the same with the group-skip branches kept.  6 = 4 with ONE A register per tap: lane l < 16 carries the flag
-    // of pixel l, and the instruction's A-broadcast field (CBSZ = 4: all 16 blocks read the A values of block ABID)
-    // picks group g's four lanes -- two VALU operations per tap instead of two per group.
-    constexpr bool MFMA = (SKIP >= 4 && SKIP <= 6);
-    static_assert(SKIP <= 7 && (SKIP != 7 || QR == 2), "");
+    // kernel already has, at the same 256 FMA per 8 cycles per SIMD -- on the other pipe, with no flag rows to fetch
+    // through the scalar cache (the flags are two VALU operations on the membership mask).  4 = every group, no branch
+    // in the tap loop; 5 = live groups only.
+    // SKIP == 6 ("four taps per instruction", free-running): v_mfma_f32_16x16x4_f32 takes A = 16 pixels x 4 taps of
+    // membership flags and B = 4 taps x 16 hypotheses and accumulates k = 0..3 in order as an exact fma chain, i.e. four
+    // in-order flagged adds for 16 pixels x 16 hypotheses per instruction.  Per group of four union taps: C 16-byte gather
+    // loads (lane l reads hypotheses 4n .. 4n + 3 of chunk j of tap l >> 4, n = l & 15), one A register built from the
+    // four membership masks, 4 * C matrix instructions, two groups in flight.  The accumulators come out in the
+    // instruction's layout (register v of lane l = pixel 4 (l >> 4) + v, hypothesis 64 j + 4 n + r for accumulator
+    // (j, r)), so this form has its own mean / store / WTA epilogue; D must be a multiple of 64.
+    // All three are measured equal to or slower than SKIP == 3: kept as independent formulations.
+    constexpr bool MM = (SKIP == 6);
+    constexpr bool MFMA = (SKIP == 4 || SKIP == 5);
     constexpr bool MSKIP = (SKIP == 5);
-    constexpr bool MBCAST = (SKIP == 6);
-    // 7 ("both pipes"): the upper row of the 2x8 tile accumulates on the matrix pipe (6 MFMA per tap, A broadcast, no
-    // branch), the lower row on the vector pipe as in SKIP == 3 (flag row fetched one tap ahead, two group-skip
-    // branches): the two halves of a tap's FMAs issue to different pipes, which run side by side across waves.
-    constexpr bool HYB = (SKIP == 7);
-    constexpr bool SYNC = (SKIP >= 3);                   // 3 .. 7 all walk in lock-step
+    static_assert(SKIP <= 6 && (!MM || (QR == 2 && FULL)), "");
+    constexpr bool SYNC = (SKIP >= 3 && SKIP <= 5);      // 3 .. 5 walk in lock-step
     constexpr bool PREF = (SKIP >= 2);                   // flag rows fetched one tap ahead + per-axis tables
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -754,33 +755,26 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     const int dl = lane * C;
     typedef float f4 __attribute__((ext_vector_type(4)));
     f2 acc[MFMA ? 1 : NPIX / 2][C];
-    f4 macc[(MFMA || HYB) ? NPIX / 4 : 1][C];              // matrix formulation: group g = pixels 4g .. 4g + 3, register i = pixel 4g + i
+    f4 macc[MFMA ? NPIX / 4 : 1][C];                       // matrix formulation: group g = pixels 4g .. 4g + 3, register i = pixel 4g + i
 #pragma unroll
     for (int j = 0; j < (MFMA ? 1 : NPIX / 2); j++)
 #pragma unroll
         for (int k = 0; k < C; k++) acc[j][k] = f2{0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < ((MFMA || HYB) ? NPIX / 4 : 1); j++)
+    for (int j = 0; j < (MFMA ? NPIX / 4 : 1); j++)
 #pragma unroll
         for (int k = 0; k < C; k++) macc[j][k] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    f4 mm[MM ? 4 * C : 1];                                 // accumulator (j, r) = mm[4 j + r]
+#pragma unroll
+    for (int j = 0; j < (MM ? 4 * C : 1); j++) mm[j] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int mm_k = lane >> 4, mm_n = lane & 15;          // tap of the group / hypothesis quad this lane feeds
+    const int mm_shift = mm_n + 16 * (mm_k & 1);           // its flag bit in the packed mask pair
     // bit of the membership mask that lane l turns into its A operand for group g: 4g + (l & 3)
     int mshift[MFMA ? NPIX / 4 : 1];
 #pragma unroll
     for (int g = 0; g < (MFMA ? NPIX / 4 : 1); g++) mshift[g] = 4 * g + (lane & 3);
-    const int mshift16 = lane & 15;
     auto mfma_flagged = [&](unsigned m, const float (&x)[C]) {
         if constexpr (!MFMA) return;
-        if constexpr (MBCAST) {
-            const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                macc[0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[0][c], 4, 0, 0);
-                if (NPIX > 4) macc[MFMA && NPIX > 4 ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 4 ? 1 : 0][c], 4, 1, 0);
-                if (NPIX > 8) macc[MFMA && NPIX > 8 ? 2 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 8 ? 2 : 0][c], 4, 2, 0);
-                if (NPIX > 8) macc[MFMA && NPIX > 8 ? 3 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[MFMA && NPIX > 8 ? 3 : 0][c], 4, 3, 0);
-            }
-            return;
-        }
 #pragma unroll
         for (int g = 0; g < NPIX / 4; g++) {
             auto body = [&]() {
@@ -882,25 +876,6 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
         }
     };
 
-    auto hyb_flagged = [&](unsigned m, const f8 &F1, const float (&x)[C]) {
-        if constexpr (!HYB) return;
-        const float A = __int_as_float(__builtin_amdgcn_sbfe(m, mshift16, 1) & 0x3f800000);   // lanes 0..7: the upper row's flags
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            macc[0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[0][c], 4, 0, 0);
-            macc[HYB ? 1 : 0][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(A, x[c], macc[HYB ? 1 : 0][c], 4, 1, 0);
-        }
-        const unsigned mb = (m >> 8) & 255u;
-        auto pair = [&](int j) {
-            const f2 fl = f2{F1[2 * j], F1[2 * j + 1]};
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                acc[HYB ? 4 + j : 0][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[HYB ? 4 + j : 0][c]);
-        };
-        if (mb & 0x0fu) { pair(0); pair(1); }
-        if (mb & 0xf0u) { pair(2); pair(3); }
-    };
-
     // box whose positions are enumerated: the wave's own bounding box, or (SYNC) the common one of the four
     // waves in workgroup coordinates (wave-relative position = workgroup-relative - (ooff, ioff))
     int bo0 = omin, bo1 = omax, bi0 = imin, bi1 = imax;
@@ -993,18 +968,7 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
-                if constexpr (HYB) {
-                    f8 F1[2];
-                    F1[0] = *reinterpret_cast<const f8 *>(member + ((m[0] >> 8) & 255u) * 8u);
-#pragma unroll
-                    for (int k = 0; k < GG; k++) {
-                        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this tap's flag row is in
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (k + 1 < GG) F1[(k + 1) & 1] = *reinterpret_cast<const f8 *>(member + ((m[k + 1] >> 8) & 255u) * 8u);
-                        __builtin_amdgcn_sched_barrier(0);
-                        hyb_flagged(m[k], F1[k & 1], x[k]);
-                    }
-                } else if constexpr (MFMA) {
+                if constexpr (MFMA) {
                     __builtin_amdgcn_sched_barrier(0);               // every load of the group is issued before its first use
 #pragma unroll
                     for (int k = 0; k < GG; k++) mfma_flagged(m[k], x[k]);
@@ -1025,9 +989,70 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
                 }
             };
             int cnt = __builtin_popcountll(live);
-            for (; cnt >= G; cnt -= G) group(std::integral_constant<int, G>{}, std::false_type{});
-            if (G == 8 && cnt > 4) group(std::integral_constant<int, G>{}, std::true_type{});
-            else if (cnt > 0) group(std::integral_constant<int, 4>{}, std::true_type{});
+            if constexpr (MM) {
+                // groups of four union taps (the last one padded with repeats of its last tap under an all-zero mask),
+                // two in flight: the gather loads of group g + 1 are issued before the matrix instructions of group g
+                auto prep = [&](i4v (&xb)[C], float &A) {
+                    unsigned o[4], m[4];
+                    int last = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool valid = live != 0;
+                        if (valid) last = next();
+                        o[k] = (unsigned)__builtin_amdgcn_readlane((int)offs, last);
+                        m[k] = valid ? (unsigned)__builtin_amdgcn_readlane((int)mask, last) : 0u;
+                    }
+                    // lane l gathers from tap l >> 4: its 16 bytes of each 256-byte chunk of that tap's row
+                    unsigned vo = o[0];
+                    vo = mm_k >= 1 ? o[1] : vo;
+                    vo = mm_k >= 2 ? o[2] : vo;
+                    vo = mm_k >= 3 ? o[3] : vo;
+                    vo += (unsigned)mm_n * 16u;
+#pragma unroll
+                    for (int j = 0; j < C; j++) xb[j] = buf_ld4(rsrc, vo, 256u * j);
+                    const unsigned m01 = m[0] | (m[1] << 16), m23 = m[2] | (m[3] << 16);
+                    A = __int_as_float(__builtin_amdgcn_sbfe((mm_k < 2) ? m01 : m23, mm_shift, 1) & 0x3f800000);
+                };
+                auto fire = [&](const i4v (&xb)[C], float A) {
+#pragma unroll
+                    for (int j = 0; j < C; j++) {
+                        mm[MM ? 4 * j + 0 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, __int_as_float(xb[j].x), mm[MM ? 4 * j + 0 : 0], 0, 0, 0);
+                        mm[MM ? 4 * j + 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, __int_as_float(xb[j].y), mm[MM ? 4 * j + 1 : 0], 0, 0, 0);
+                        mm[MM ? 4 * j + 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, __int_as_float(xb[j].z), mm[MM ? 4 * j + 2 : 0], 0, 0, 0);
+                        mm[MM ? 4 * j + 3 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, __int_as_float(xb[j].w), mm[MM ? 4 * j + 3 : 0], 0, 0, 0);
+                    }
+                };
+                int ng = (cnt + 3) >> 2;
+                if (ng > 0) {
+                    i4v xa[C], xc[C];
+                    float Aa, Ac;
+                    prep(xa, Aa);
+                    ng--;
+                    while (ng >= 2) {
+                        prep(xc, Ac);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fire(xa, Aa);
+                        __builtin_amdgcn_sched_barrier(0);
+                        prep(xa, Aa);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fire(xc, Ac);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ng -= 2;
+                    }
+                    if (ng == 1) {
+                        prep(xc, Ac);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fire(xa, Aa);
+                        fire(xc, Ac);
+                    } else {
+                        fire(xa, Aa);
+                    }
+                }
+            } else {
+                for (; cnt >= G; cnt -= G) group(std::integral_constant<int, G>{}, std::false_type{});
+                if (G == 8 && cnt > 4) group(std::integral_constant<int, G>{}, std::true_type{});
+                else if (cnt > 0) group(std::integral_constant<int, 4>{}, std::true_type{});
+            }
             if (SYNC) __builtin_amdgcn_s_barrier();      // time alignment only: nothing is exchanged through memory
         }
     } else if (lane == 0) atomicOr(ub_flag, 1);
@@ -1054,15 +1079,71 @@ __global__ void __launch_bounds__(NT, (SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 
     // accumulators are read with static register numbers; pixels that need the plain walk (reference UB,
     // or a NaN the flag arithmetic may have produced) are collected and handled by one rolled loop
     unsigned redo = 0;
+    if constexpr (MM) {
+        // lane l holds, for each of its four pixels q = 4 (l >> 4) + v, the hypotheses 64 j + 4 n + r (n = l & 15)
+        const int myc = ((int)(pk_o >> 16) - (int)(pk_o & 0xffffu) + 1) * ((int)(pk_i >> 16) - (int)(pk_i & 0xffffu) + 1);   // lane q: taps of pixel q
 #pragma unroll
-    for (int q = 0; q < NPIX; q++) {
+        for (int v = 0; v < 4; v++) {
+            const int q = 4 * mm_k + v;
+            const bool have = (q >> TWS) < nrow && (q & (QC - 1)) < ncol;
+            const float fc = (float)__builtin_amdgcn_ds_bpermute(q << 2, myc);
+            const int p = p0 + (q >> TWS) * W + (q & (QC - 1));
+            f4 mean[C];
+            bool bad = ub;
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const f4 a = f4{mm[MM ? 4 * j : 0][v], mm[MM ? 4 * j + 1 : 0][v], mm[MM ? 4 * j + 2 : 0][v], mm[MM ? 4 * j + 3 : 0][v]};
+                bad = bad || (a.x != a.x) || (a.y != a.y) || (a.z != a.z) || (a.w != a.w);
+                mean[j] = f4{a.x / fc, a.y / fc, a.z / fc, a.w / fc};
+            }
+            // a pixel with a NaN anywhere in its row (or a reference-undefined tile) goes to the plain walk below
+            const unsigned long long bal = __ballot(bad && have);
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if ((bal >> (16 * g)) & 0xffffull) redo |= 1u << (4 * g + v);
+            const bool mine_bad = ((bal >> (16 * mm_k)) & 0xffffull) != 0;
+            if (have && !mine_bad) {
+                float *dst = vout + (size_t)p * D + 4 * mm_n;
+#pragma unroll
+                for (int j = 0; j < C; j++) __builtin_nontemporal_store(mean[j], reinterpret_cast<f4 *>(dst + 64 * j));
+            }
+            if (disp) {
+                // first strict minimum over d (CrossArm.cpp:44-52): the lane's own candidates in increasing d, then the
+                // lexicographic minimum of (key, d) over the 16 lanes of the row; NaN keys sort last, a NaN at d = 0 wins
+                unsigned bk = 0xFFFFFFFFu; int bd = 0;
+#pragma unroll
+                for (int j = 0; j < C; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float x = mean[j][r];
+                        const unsigned key = (x != x) ? 0xFFFFFFFFu : f32_key(x);
+                        const int d = 64 * j + 4 * mm_n + r;
+                        if ((j == 0 && r == 0) || key < bk) { bk = key; bd = d; }
+                    }
+                auto step = [&](auto ctrl) {
+                    constexpr int CTRL = decltype(ctrl)::value;
+                    const unsigned ok = (unsigned)__builtin_amdgcn_update_dpp((int)bk, (int)bk, CTRL, 0xF, 0xF, false);
+                    const int od = __builtin_amdgcn_update_dpp(bd, bd, CTRL, 0xF, 0xF, false);
+                    if (ok < bk || (ok == bk && od < bd)) { bk = ok; bd = od; }
+                };
+                step(std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+                step(std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+                step(std::integral_constant<int, 0x141>{});    // row_half_mirror
+                step(std::integral_constant<int, 0x140>{});    // row_mirror: every lane of the row holds the row's minimum
+                const float m0 = mean[0][0];
+                const int nan0 = __builtin_amdgcn_ds_bpermute((16 * mm_k) << 2, (int)(m0 != m0));   // lane n = 0 of the row owns d = 0
+                if (have && !mine_bad && mm_n == 0) disp[p] = (float)(nan0 ? 0 : bd);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < (MM ? 0 : NPIX); q++) {
         if ((q >> TWS) >= nrow || (q & (QC - 1)) >= ncol) continue;
         float a[C];
         bool bad = ub;
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            a[k] = (MFMA || (HYB && q < 8)) ? macc[(MFMA || (HYB && q < 8)) ? q / 4 : 0][k][q & 3]
-                                            : ((q & 1) ? acc[MFMA ? 0 : q / 2][k].y : acc[MFMA ? 0 : q / 2][k].x);
+            a[k] = MFMA ? macc[MFMA ? q / 4 : 0][k][q & 3] : ((q & 1) ? acc[MFMA ? 0 : q / 2][k].y : acc[MFMA ? 0 : q / 2][k].x);
             bad = bad || (a[k] != a[k]);
         }
         if (__ballot(bad)) { redo |= 1u << q; continue; }
@@ -1454,15 +1535,24 @@ static void launch_agg_multi(smt_crossarm *h, const float *vin, float *vout, flo
 #define SMT_AGGM(CC, FF)                                                                                  \
     hipLaunchKernelGGL((k_aggregate_multi<CC, ORDER, FF, QR, SKIP, TWS>), grid, dim3(NT), (size_t)h->occ_lds, h->stream, vin, vout, h->H, h->W, \
                        h->D, h->arm[0], h->arm[1], h->arm[2], h->arm[3], disp, ub, SW, h->member, h->sweep)
-    switch (C * 2 + (full ? 1 : 0)) {
-    case 2: SMT_AGGM(1, false); break;
-    case 3: SMT_AGGM(1, true); break;
-    case 4: SMT_AGGM(2, false); break;
-    case 5: SMT_AGGM(2, true); break;
-    case 6: SMT_AGGM(3, false); break;
-    case 7: SMT_AGGM(3, true); break;
-    case 8: SMT_AGGM(4, false); break;
-    default: SMT_AGGM(4, true); break;
+    if constexpr (SKIP == 6) {
+        switch (C) {                                       // D is a multiple of 64 here (smt_crossarm_aggregate)
+        case 1: SMT_AGGM(1, true); break;
+        case 2: SMT_AGGM(2, true); break;
+        case 3: SMT_AGGM(3, true); break;
+        default: SMT_AGGM(4, true); break;
+        }
+    } else {
+        switch (C * 2 + (full ? 1 : 0)) {
+        case 2: SMT_AGGM(1, false); break;
+        case 3: SMT_AGGM(1, true); break;
+        case 4: SMT_AGGM(2, false); break;
+        case 5: SMT_AGGM(2, true); break;
+        case 6: SMT_AGGM(3, false); break;
+        case 7: SMT_AGGM(3, true); break;
+        case 8: SMT_AGGM(4, false); break;
+        default: SMT_AGGM(4, true); break;
+        }
     }
 #undef SMT_AGGM
 }
@@ -1555,14 +1645,15 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     // groups of 4 pixels (= tile rows) without a member skipped, flag rows prefetched, per-axis membership tables, the
     // four waves of a workgroup (8 x 8 pixels) in lock-step (default); 7 = the same with 2x8 tiles (round 2's default);
     // 6 = 7 free-running; 4 = 6 with flags per live group and pixel-by-pixel classification; 5 = 4 without the skip;
-    // 3 = 1x8 pixels, no skip; 8 / 9 / 10 = 7 with the flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1: every
-    // group / live groups only / one A register per tap through the broadcast field); 11 = upper tile row on the matrix
-    // pipe, lower row on the vector pipe; 13 = 9 with 4x4 tiles; 0 = 4 adjacent pixels per wave with a 16-way switch on
-    // the membership mask; 1 = plain one-pixel-per-wave walk (also the form used for volumes >= 4 GiB, for D > 256 and
-    // for order 2); 2 = pipelined one-pixel-per-wave walk.  All but 1 address taps with 32-bit byte offsets.
+    // 3 = 1x8 pixels, no skip; 8 / 9 = 7 with the flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1: every
+    // group / live groups only), 11 = 9 with 4x4 tiles, 10 = four taps per v_mfma_f32_16x16x4 (4x4 tiles, free-running);
+    // 0 = 4 adjacent pixels per wave with a 16-way switch on the membership mask; 1 = plain one-pixel-per-wave walk
+    // (also the form used for volumes >= 4 GiB, for D > 256 and for order 2); 2 = pipelined one-pixel-per-wave walk.
+    // All but 1 address taps with 32-bit byte offsets.
     int variant = h->variant;
     if (variant != 1 && (size_t)h->H * h->W * h->D * 4 >= ((size_t)1 << 32)) variant = 1;
     if (h->D > 256) variant = 1;                          // 5..8 hypotheses per lane: the plain walk only
+    if (variant == 10 && (h->D % 64 != 0 || ((uintptr_t)vin & 15) != 0)) variant = 12;   // the four-taps form gathers whole 16-byte quads
     if (order == 2) { launch_agg<2>(h, vin, vout, disp); SMT_LAUNCH_CHECK(); return SMT_OK; }   // inactive sibling: plain walk only
     if (variant == 0) { if (order == 0) launch_agg_quad<0, 4>(h, vin, vout, disp); else launch_agg_quad<1, 4>(h, vin, vout, disp); }
     else if (variant == 1) { if (order == 0) launch_agg<0>(h, vin, vout, disp); else launch_agg<1>(h, vin, vout, disp); }
@@ -1573,10 +1664,9 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 7) { if (order == 0) launch_agg_multi<0, 2, 3>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3>(h, vin, vout, disp); }
     else if (variant == 8) { if (order == 0) launch_agg_multi<0, 2, 4>(h, vin, vout, disp); else launch_agg_multi<1, 2, 4>(h, vin, vout, disp); }
     else if (variant == 9) { if (order == 0) launch_agg_multi<0, 2, 5>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5>(h, vin, vout, disp); }
-    else if (variant == 10) { if (order == 0) launch_agg_multi<0, 2, 6>(h, vin, vout, disp); else launch_agg_multi<1, 2, 6>(h, vin, vout, disp); }
-    else if (variant == 11) { if (order == 0) launch_agg_multi<0, 2, 7>(h, vin, vout, disp); else launch_agg_multi<1, 2, 7>(h, vin, vout, disp); }
+    else if (variant == 10) { if (order == 0) launch_agg_multi<0, 2, 6, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 6, 2>(h, vin, vout, disp); }
+    else if (variant == 11) { if (order == 0) launch_agg_multi<0, 2, 5, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5, 2>(h, vin, vout, disp); }
     else if (variant == 12) { if (order == 0) launch_agg_multi<0, 2, 3, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3, 2>(h, vin, vout, disp); }
-    else if (variant == 13) { if (order == 0) launch_agg_multi<0, 2, 5, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5, 2>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1584,7 +1674,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 13) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 12) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->variant = variant;
     // the lock-step kernel wants its four waves stacked vertically (8 columns x 8 rows per workgroup: the
