@@ -176,8 +176,8 @@ def extra_configs(dev, reps=5):
     out["cfg1_sad5x5_450x375_d64"] = {"ms_per_view": round(ms, 4), "Mdisp_s": round(H * W * D / ms / 1e3, 1),
                                       "bound": "valu-int (volume never stored)", "alg_byte_sads_per_view": taps,
                                       "frac_valu_sad_u8_peak": round(taps / (ms * 1e-3) / SAD_U8_PER_S, 4),
-                                      "note": "10.8 M hypotheses in all: one wave per pixel, ten unaligned dword loads per lane and pixel; "
-                                              "the launch is latency bound, not VALU bound (DESIGN.md 4)"}
+                                      "note": "10.8 M hypotheses in all (a 0.06 ms launch): window rows staged in LDS as byte-shifted dword "
+                                              "copies, tap loop = LDS reads + v_sad_u8; 0.065 of the peak at 1080p D=128 9x9 (DESIGN.md 4)"}
 
     # ---- configs 2 and 5: AD-Census both views + WTA ---------------------------------------------
     for key, (H, W, D, seed, P) in {"cfg2_adcensus_720p_d128": (720, 1280, 128, 2, 8),
@@ -219,13 +219,15 @@ def extra_configs(dev, reps=5):
         a = [m.double() for m in ca.arm_maps()]
         area[nm] = float(((a[0] + a[1] + 1) * (a[2] + a[3] + 1)).mean())
     aggL, aggR = torch.empty((H, W, D), device=dev), torch.empty((H, W, D), device=dev)
-    st["aggregate_left"] = ev_timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL, dL), reps)
-    st["aggregate_right"] = ev_timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), reps)
+    # warm = 4: the first ~20 ms of a kernel on freshly allocated volumes run ~8 % slow (tools/agg_time.py, interleaved
+    # rounds); the stage times are steady-state times
+    st["aggregate_left"] = ev_timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL, dL), reps, warm=4)
+    st["aggregate_right"] = ev_timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), reps, warm=4)
     caL.status()
     caR.status()
     so = smt.ScanlineOptimizer().Initialize(H, W, D, 10, 150, dev)
     sout = torch.empty((H, W, D), device=dev)
-    st["scanline"] = ev_timed(lambda: so.ScanLine(aggL, Lf, sout, dL), reps)
+    st["scanline"] = ev_timed(lambda: so.ScanLine(aggL, Lf, sout, dL), reps, warm=3)
     dLc = dL.clone()
     st["lrcheck"] = ev_timed(lambda: (dLc.copy_(dL), smt.LeftRightConsistency(W, H, 2, dLc, dR)), reps)
     total = sum(st.values())

@@ -484,6 +484,10 @@ int smt_adcensus_option_aggregate(const smt_adcensus_option *o, const uint8_t *b
  * window side 2w+1.  disp: int32 [H][W] (right view leaves the last row/column 0). */
 int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winsize, int view,
             int32_t *disp, void *stream);
+/* Test hook (process-wide): 2 = window rows staged in LDS as byte-shifted dword copies, 32 pixels per workgroup
+ * (default for windows of side >= 4), 1 = one wave per pixel straight from global memory (first formulation, and the
+ * fallback for 3x3 windows).  Identical results. */
+int smt_sad_set_impl(int impl);
 /* CrossCheckDiaparity (Sad.h:184-222).  out int32 [H][W] (invalid = INT32_MIN, the x86
  * value of the reference's int(inf)); cls as smt_lrcheck. */
 int smt_sad_crosscheck(const int32_t *dispL, const int32_t *dispR, int H, int W, int32_t *out,

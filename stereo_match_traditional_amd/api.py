@@ -13,7 +13,7 @@ from ._lib import check, lib, VIEW_LEFT, VIEW_RIGHT, VIEW_BOTH
 
 __all__ = ["FillTheHole", "chooseArmLengthLeft", "chooseArmLengthRight", "chooseArmLengthUp", "chooseArmLengthDown", "costAggregationNew", "AD_Census", "wta", "current_stream_ptr", "CrossArmAggregation", "cblsm_ComputeAD",
            "ScanlineOptimizer", "LeftRightConsistency", "LeftAndRightConsistency", "CrossAggregator", "GetPointDepthLeft",
-           "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "ncc_set_impl", "asw_masks",
+           "GetPointDepthRight", "sad_CrossCheckDiaparity", "NCC_algorithem", "ncc_set_impl", "sad_set_impl", "asw_masks",
            "AdaptiveSupportWeight", "sad_batch", "ncc_batch", "asw_batch", "asw_set_impl", "asw_CrossCheckDiaparity", "cvtColor_BGR2GRAY", "copyMakeBorder_replicate",
            "to_float", "MedianFilter", "RemoveSpeckles", "imread", "imwrite", "ADCensusOption", "adcensus_option_aggregate", "Pipeline", "scratch_trim", "scratch_info"]
 
@@ -671,6 +671,11 @@ def NCC_algorithem(leftImage, rigthImage, winSize, dispRange, want_cost=False):
     check(lib().smt_ncc(_ptr(leftImage), _ptr(rigthImage), H, W, dispRange, winSize, _ptr(disp), _ptr(cost),
                         current_stream_ptr()), "smt_ncc")
     return (disp, cost) if want_cost else disp
+
+
+def sad_set_impl(impl):
+    """2 = LDS-staged SAD kernel (default), 1 = first formulation (test hook)."""
+    check(lib().smt_sad_set_impl(int(impl)), "smt_sad_set_impl")
 
 
 def ncc_set_impl(impl):

@@ -72,10 +72,11 @@ template <> struct vecf<3> { float v[3]; };
 template <> struct __attribute__((aligned(16))) vecf<4> { float v[4]; };
 
 // Cache policy of the volume traffic (compile-time, A/B builds): SMT_SCAN_NT & 1 = non-temporal loads, & 2 =
-// non-temporal stores.  Every byte a pass touches is used once per pass, so nothing is lost by not keeping it;
-// what it changes is how much of the L2 / Infinity Cache a kernel running BESIDE the scanline keeps.
+// non-temporal stores.  Every byte a pass touches is used once per pass, so nothing is lost by not keeping it.
+// Measured at 1080p x 192 (tools/scan_time.py, alternating processes on one box): 3.38 -> 3.23, 3.42 -> 3.27,
+// 3.35 -> 3.34 ms for the three passes together with both: the default.
 #ifndef SMT_SCAN_NT
-#define SMT_SCAN_NT 0
+#define SMT_SCAN_NT 3
 #endif
 // row of C consecutive floats per lane; FULL (D == 64*C): one unpredicated vector access
 template <int C, bool FULL>

@@ -130,6 +130,127 @@ __global__ void __launch_bounds__(NT) k_sad(const uint8_t *__restrict__ Lp, cons
     if (lane == 0) disp[p] = out;
 }
 
+// Second formulation (default for windows of side >= 4): k_sad above is bound by its own global-load latency (one
+// wave per pixel, ten unaligned dword loads per lane and pixel at 5x5; 0.8 % of the v_sad_u8 rate at config 1).
+// Here a workgroup owns STP consecutive pixels of a row and stages, once, the `side` rows of the anchor image over
+// its pixels and of the other image over every window position its hypotheses can touch -- each as FOUR byte-shifted
+// dword arrays (copy s, word j = bytes 4j + s .. 4j + s + 3), so that the four bytes at any byte address A are the
+// aligned dword copy[A & 3][A >> 2].  The tap loop is then LDS reads + v_sad_u8 only: per window row and group of four
+// columns one uniform (broadcast) read of the anchor dword and one read per hypothesis slot, lanes with consecutive d
+// hitting the four copies in turn (copy strides are 8 banks apart: conflict-free).  Sums, masks and the selection rules
+// are those of k_sad; the two are compared bit for bit in the tests.
+constexpr int STP = 32;                                   // pixels per workgroup (8 per wave)
+
+template <int K>
+__global__ void __launch_bounds__(NT) k_sad2(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H, int W,
+                                             int D, int w, int view, int32_t *__restrict__ disp, int ALW, int OLW)
+{
+    extern __shared__ unsigned s_sad[];
+    const int side = 2 * w + 1, Wp = W + 2 * w;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int io = blockIdx.y, jo0 = blockIdx.x * STP;
+    // ALW / OLW: dwords per copy row of the anchor / other image, both = 8 (mod 32) so that the four copies of a row
+    // start 8 banks apart
+    unsigned *s_a = s_sad;                                 // [side][4][ALW]
+    unsigned *s_o = s_sad + (size_t)side * 4 * ALW;        // [side][4][OLW]
+    const uint8_t *Aimg = (view == 0 ? Lp : Rp) + (size_t)io * Wp;
+    const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
+    // first byte column staged of the other image: view 0: jo0 - (64 K - 1) .. ; view 1: jo0 ..
+    const int xbase = (view == 0) ? jo0 - (64 * K - 1) : jo0;
+    auto stage = [&](unsigned *dst, const uint8_t *img, int x0, int LW) {
+        // one thread per dword column j of a row: bytes x0 + 4j .. x0 + 4j + 7 as two (unaligned) dword loads, the four
+        // shifted copies from them by v_alignbyte; columns that touch the image edge are assembled byte by byte with
+        // the column clamped (bytes no hypothesis uses: any in-image value)
+        for (int e = threadIdx.x; e < side * LW; e += NT) {
+            const int r = e / LW, j = e - r * LW;
+            const uint8_t *row = img + (size_t)r * Wp;
+            const int x = x0 + 4 * j;
+            unsigned lo, hi;
+            if (x >= 0 && x + 7 <= Wp - 1) {
+                __builtin_memcpy(&lo, row + x, 4);
+                __builtin_memcpy(&hi, row + x + 4, 4);
+            } else {
+                lo = hi = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int xa = x + b, xb = x + 4 + b;
+                    xa = xa < 0 ? 0 : (xa > Wp - 1 ? Wp - 1 : xa);
+                    xb = xb < 0 ? 0 : (xb > Wp - 1 ? Wp - 1 : xb);
+                    lo |= (unsigned)row[xa] << (8 * b);
+                    hi |= (unsigned)row[xb] << (8 * b);
+                }
+            }
+            unsigned *d = dst + (size_t)r * 4 * LW + j;
+            d[0] = lo;
+            d[LW] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+            d[2 * LW] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+            d[3 * LW] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+        }
+    };
+    stage(s_a, Aimg, jo0, ALW);
+    stage(s_o, Bimg, xbase, OLW);
+    __syncthreads();
+
+    const int nfull = side >> 2, rem = side & 3;
+    const unsigned tmask = rem ? (0xffffffffu << (8 * (4 - rem))) : 0u;
+    for (int p = wv; p < STP; p += NT / 64) {
+        const int jo = jo0 + p;
+        if (jo >= W) break;
+        const int pix = io * W + jo;
+        if (view == 1 && (io >= H - 1 || jo >= W - 1)) {                  // never written (:157,:160)
+            if (lane == 0) disp[pix] = 0;
+            continue;
+        }
+        const int dmax = (view == 0) ? jo : (W - 1 - jo);                 // last in-range disparity
+        // dword index, inside a row's block of four copies, of the window's first full group and of its tail group
+        // (columns side - 4 .. side - 1): a full group g is then just "+ g", so the tap loop has no address arithmetic
+        int bfull[K], btail[K];
+        unsigned acc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int d = lane + 64 * k;
+            const int dd = d < dmax ? d : dmax;
+            const int xs = ((view == 0) ? jo - dd : jo + dd) - xbase, xt = xs + side - 4;
+            bfull[k] = (xs & 3) * OLW + (xs >> 2);
+            btail[k] = (xt & 3) * OLW + (xt >> 2);
+            acc[k] = 0;
+        }
+        const int afull = (p & 3) * ALW + (p >> 2), at = p + side - 4, atail = (at & 3) * ALW + (at >> 2);
+        for (int r = 0; r < side; r++) {
+            const unsigned *ra = s_a + (size_t)r * 4 * ALW, *ro = s_o + (size_t)r * 4 * OLW;
+            for (int g = 0; g < nfull; g++) {
+                const unsigned a4 = ra[afull + g];
+#pragma unroll
+                for (int k = 0; k < K; k++) acc[k] = __builtin_amdgcn_sad_u8(a4, ro[bfull[k] + g], acc[k]);
+            }
+            if (rem) {
+                // the last dword ends at the row's last byte; the bytes already counted are masked out of both operands
+                const unsigned a4 = ra[atail] & tmask;
+#pragma unroll
+                for (int k = 0; k < K; k++) acc[k] = __builtin_amdgcn_sad_u8(a4, ro[btail[k]] & tmask, acc[k]);
+            }
+        }
+        float sad[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++) sad[k] = (k < K && lane + 64 * k < D) ? (float)acc[k < K ? k : 0] : 0.0f;   // sadvalue :15-20
+        int out;
+        if (view == 0) out = sad_optimal(sad, D, lane);
+        else {                                                            // GetMinSadIndex :22-38
+            float lm = INFINITY; int ld = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int d = lane + 64 * k;
+                if (d < D && sad[k] < lm) { lm = sad[k]; ld = d; }
+            }
+            const float mn = wave_min_nonneg(lm);
+            int cand = (lm == mn) ? ld : 0x7fffffff;
+            out = (int)wave_min_u32((unsigned)cand);
+        }
+        if (lane == 0) disp[pix] = out;
+    }
+}
+
 // ---------------------------------------------------------------------------------- NCC
 __device__ double ncc_cost(const uint8_t *a, const uint8_t *b, int W, int side)   // NCC.h:15-49
 {
@@ -881,6 +1002,14 @@ SMT_API int smt_asw_set_impl(int impl)
     return SMT_OK;
 }
 
+static int g_sad_impl = 2;   // 2: k_sad2 (rows staged in LDS as byte-shifted dword copies; default), 1: k_sad (one wave per pixel from global memory)
+SMT_API int smt_sad_set_impl(int impl)
+{
+    if (impl != 1 && impl != 2) return SMT_ERR_ARG;
+    g_sad_impl = impl;
+    return SMT_OK;
+}
+
 SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, int winsize, int view,
                     int32_t *disp, void *stream)
 {
@@ -888,8 +1017,24 @@ SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         (view != SMT_VIEW_LEFT && view != SMT_VIEW_RIGHT))
         return SMT_ERR_ARG;
     const int N = H * W;
-    hipLaunchKernelGGL(k_sad, dim3((N + 3) / 4), dim3(NT), 0, smt_stream(stream), Lp, Rp, H, W, D, winsize + 1,
-                       view == SMT_VIEW_LEFT ? 0 : 1, disp);
+    const int w = winsize + 1, side = 2 * w + 1, K = (D + 63) / 64, v = view == SMT_VIEW_LEFT ? 0 : 1;
+    // copy-row lengths in dwords, rounded up to 8 (mod 32): anchor bytes jo0 .. jo0 + STP + side - 2, other image
+    // 64 K - 1 more
+    auto copy_words = [](int bytes) { int n = (bytes + 3) / 4 + 1; return n + ((8 - n % 32) % 32 + 32) % 32; };
+    const int ALW = copy_words(STP + side - 1), OLW = copy_words(STP + side - 1 + 64 * K - 1);
+    const size_t shm = (size_t)side * 4 * (ALW + OLW) * 4;
+    if (g_sad_impl == 2 && side >= 4 && shm <= 64 * 1024) {
+        const dim3 grid((W + STP - 1) / STP, H);
+        switch (K) {
+        case 1: hipLaunchKernelGGL(k_sad2<1>, grid, dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, w, v, disp, ALW, OLW); break;
+        case 2: hipLaunchKernelGGL(k_sad2<2>, grid, dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, w, v, disp, ALW, OLW); break;
+        case 3: hipLaunchKernelGGL(k_sad2<3>, grid, dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, w, v, disp, ALW, OLW); break;
+        default: hipLaunchKernelGGL(k_sad2<4>, grid, dim3(NT), shm, smt_stream(stream), Lp, Rp, H, W, D, w, v, disp, ALW, OLW); break;
+        }
+        SMT_LAUNCH_CHECK();
+        return SMT_OK;
+    }
+    hipLaunchKernelGGL(k_sad, dim3((N + 3) / 4), dim3(NT), 0, smt_stream(stream), Lp, Rp, H, W, D, w, v, disp);
     SMT_LAUNCH_CHECK();
     return SMT_OK;
 }
