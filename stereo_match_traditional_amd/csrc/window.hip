@@ -975,12 +975,6 @@ __global__ void __launch_bounds__(A3P * 64, (K * A3Q <= 4 ? 8 : 4)) k_asw4(const
     // (the anchor phase of a tile reads both after the barrier that follows its window staging)
     const int tpr = (W + NPX - 1) / NPX, ntiles = tpr * H;
     double *slot = slots + (size_t)blockIdx.x * NPX * side * side;
-#ifdef SMT_ASW4_STAGGER
-    // experiment: the second workgroup of every CU starts about half a tile late, so that the barrier-separated
-    // table-building phases of the two do not coincide for the whole launch
-    if (blockIdx.x >= gridDim.x / 2)
-        for (int k = 0; k < SMT_ASW4_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
-#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asw3_tile<K, A3Q, true, true>(Lp, Rp, H, W, D, wins, space, slot, a32, T, view, disp, cost_out, 0, tile / tpr,
                                       (tile % tpr) * NPX, smem);
