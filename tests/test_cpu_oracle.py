@@ -592,3 +592,22 @@ def test_oracle_is_clean_under_asan_ubsan():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "oracle sanitizer run clean" in r.stdout
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/smt.h is the drop-in boundary: it must compile as C99 (no C++ or HIP types in the signatures) and a C
+    program must link against libsmt_hip.so through it."""
+    import subprocess
+    from stereo_match_traditional_amd import build
+    lib = build.build()
+    src = tmp_path / "t.c"
+    src.write_text('#include "smt.h"\n#include <stdio.h>\n'
+                   'int main(void) { smt_crossarm_params p; smt_crossarm_default_params(&p);\n'
+                   '  printf("%d %d %s\\n", smt_version(), p.tau, smt_strerror(SMT_ERR_REF_UB)); return SMT_MAX_DISPARITY == 512 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", str(src), "-I", os.path.join(ROOT, "include"),
+                        "-L", os.path.dirname(lib), "-lsmt_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split()[:2] == ["100", "30"], (r.stdout, r.stderr)
