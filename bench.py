@@ -565,7 +565,8 @@ def main():
         traffic, traffic_src = pmc_traffic(args.workload)
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_cost_fast2 (cost volume + fused WTA, both views)",
+                "kernel": "k_cost_fast2p / k_cost_fast2 (cost volume + fused WTA, both views; every launch of a batch but "
+                          "the last also carries the next pair's table workgroups)",
                 "kernel_ms": round(k_ms, 4), "tables_ms": round(float(np.mean(prep_ms)), 4),
                 "timed_launches": len(cost_ms), "timed_every": stride,
                 "algorithmic_bytes_per_launch": alg_bytes}

@@ -94,9 +94,9 @@ int smt_sum_f32(const float *x, size_t n, double *out_dev, void *stream);
 
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------
  * When enabled, every N-th pair processed on the handle records HIP events -- around the table
- * kernels on the handle's internal stream and around the cost kernel(s) on the caller's stream, i.e.
- * each on the stream the kernels are launched on -- into a ring of `SMT_TIMING_SLOTS` slots; nothing
- * synchronises until
+ * kernels and around the cost kernel(s), each on the stream the kernels are launched on -- into a ring
+ * of `SMT_TIMING_SLOTS` slots (a pair whose tables were built inside the previous pair's cost launch,
+ * smt_adcensus_compute_batch, reports ~0 for them); nothing synchronises until
  * smt_adcensus_kernel_times, which waits for the last event and returns the per-pair
  * durations in milliseconds, oldest first. */
 #define SMT_TIMING_SLOTS 1024
@@ -166,8 +166,10 @@ int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R, int vi
 /* Same, for a batch of `pairs` image pairs laid out [pairs][H][W]; the volumes are
  * reused per pair (only the last pair's stay readable), the disparity maps are
  * [pairs][H][W].  This is the sharding unit of the multi-GPU configuration.  The census tables
- * are double-buffered inside the handle and built on an internal stream, so pair b+1's table
- * kernels overlap pair b's cost kernel. */
+ * are double-buffered inside the handle: with both views and D <= 256 the table workgroups of pair
+ * b+1 are spread through the grid of pair b's cost launch (one launch per pair, one stream); single
+ * views and D > 256 build them on an internal stream beside pair b's cost kernel.  SMT_OVERLAP =
+ * 0 / 1 / 2 in the environment forces in-order / internal-stream / fused (read at every call). */
 int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
                                int views, float *dispL, float *dispR);
 

@@ -83,7 +83,7 @@ __device__ __forceinline__ void prep_edges(const float *__restrict__ Lf, const f
         const int cc = xr < 0 ? 0 : xr;
         const unsigned rc = (unsigned)(int)Rf[(size_t)i * W + cc];
         uint64_t w = 0;
-#pragma unroll
+#pragma unroll 1
         for (int r = -4; r <= 4; r++) {
             const int ii = i + r;
             const bool rv = (ii >= 0 && ii < H);
@@ -104,7 +104,7 @@ __device__ __forceinline__ void prep_edges(const float *__restrict__ Lf, const f
         const int cc = xl > W - 1 ? W - 1 : xl;          // centre clamps to W-1 (:224-225)
         const unsigned lc = (unsigned)(int)Lf[(size_t)i * W + cc];
         uint64_t w = 0;
-#pragma unroll
+#pragma unroll 1
         for (int r = -4; r <= 4; r++) {
             const int ii = i + r;
             const bool rv = (ii >= 0 && ii < H);
@@ -122,26 +122,88 @@ __device__ __forceinline__ void prep_edges(const float *__restrict__ Lf, const f
     }
 }
 
-__global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
-                                              int H, int W, Tables T)
+// Census words of PRR consecutive rows of one column of one image (IMG 0 = left, 1 = right) from the staged tile.
+// The two images are processed one after the other and a thread's rows in groups of PRR, so the live window is
+// (PRR + 8) x 2 dwords and only PRR rows' store addresses are in flight: with PRR = 1 prep_tile takes 51 VGPRs (122 in
+// the form that kept 16 rows of both images in registers) and fits beside the cost kernel it is fused with (below) at
+// 8 waves per SIMD.
+constexpr int PSC = PTW + 6;                                // staged columns (3-column halo)
+constexpr int PSW = (PSC + 2 + 3) / 4 + 1;                  // row stride in dwords (one spare for the 3rd dword)
+constexpr int PRR = 1;
+template <int IMG>
+__device__ __forceinline__ void prep_rows(const uint32_t (*__restrict__ sw)[PSW], int i0, int row0, int x, int col,
+                                          unsigned colbits, int H, int W, const Tables &T)
 {
-    constexpr int SR = PTH + 8, SC = PTW + 6;               // staged rows / columns (4-row, 3-column halo)
-    constexpr int SW = (SC + 2 + 3) / 4 + 1;                // row stride in dwords (one spare for the 3rd dword)
-    __shared__ uint32_t sLw[SR][SW];
-    __shared__ uint32_t sRw[SR][SW];
+    // The thread's 7-byte window [col, col+6] of each of the PRR+8 staged rows it needs, as two dwords: three
+    // aligned LDS dwords shifted by col%4 bytes.  Bytes past col+6 are never used.
+    const int cw = col >> 2;
+    const unsigned sh = (unsigned)(col & 3);
+    uint32_t w0[PRR + 8], w1[PRR + 8];
+#pragma unroll
+    for (int r = 0; r < PRR + 8; r++) {
+        const uint32_t a0 = sw[row0 + r][cw], a1 = sw[row0 + r][cw + 1], a2 = sw[row0 + r][cw + 2];
+        w0[r] = __builtin_amdgcn_alignbyte(a1, a0, sh); w1[r] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+    }
+#pragma unroll
+    for (int rr = 0; rr < PRR; rr++) {
+        const int i = i0 + row0 + rr;
+        if (i >= H) break;
+        // centre = byte 3 of the window of staged row rr+4
+        const int cc = (int)(w0[rr + 4] >> 24);
+        T.u8[IMG][(size_t)i * W + x] = (uint8_t)cc;
+        // census word, MSB first over taps t = r*7 + c: bit = centre > neighbour = sign of
+        // (neighbour - centre), shifted in with one v_alignbit per tap.  Taps 0..30 fill the high word
+        // (bits 62..32), taps 31..62 the low word; every staged byte is readable, the raw bits are
+        // masked afterwards with the tap-validity word.
+        uint32_t ch = 0, cl = 0;
+        uint64_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int ii = i + r - 4;
+            if (ii >= 0 && ii < H) m |= (uint64_t)colbits << (56 - 7 * r);
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                const int t = r * 7 + c;
+                const uint32_t w = c < 4 ? w0[rr + r] : w1[rr + r];
+                const int dv = (int)((w >> (8 * (c & 3))) & 0xffu) - cc;
+                if (t < 31) ch = __builtin_amdgcn_alignbit(ch, (uint32_t)dv, 31);
+                else cl = __builtin_amdgcn_alignbit(cl, (uint32_t)dv, 31);
+            }
+        }
+        const uint64_t cen = (((uint64_t)ch << 32) | cl) & m;
+        const size_t p = (size_t)i * W + x;
+        T.cenA[IMG][p] = cen;
+        if (IMG == 0) {
+            T.mask[p] = m;
+            if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cen;      // cenX_L index = xl
+        } else {
+            if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cen;      // cenX_R index = xr + 3
+        }
+    }
+}
+
+// One workgroup of the table launch: (bx, by) of a (gdx, ...) grid -- a 64 x 32 tile, or past the tile rows a block
+// of border columns.  Called with workgroup-uniform arguments by k_prep and by the table workgroups of k_cost_fast2p.
+__device__ __forceinline__ void prep_tile(const float *__restrict__ Lf, const float *__restrict__ Rf, int H, int W,
+                                          const Tables &T, int bx, int by, int gdx)
+{
+    constexpr int SR = PTH + 8;                             // staged rows (4-row halo)
+    __shared__ uint32_t sLw[SR][PSW];
+    __shared__ uint32_t sRw[SR][PSW];
     const int tiles_y = (H + PTH - 1) / PTH;
-    if ((int)blockIdx.y >= tiles_y) {                       // workgroup-uniform, before any barrier
-        prep_edges(Lf, Rf, H, W, T, ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x);
+    if (by >= tiles_y) {                                    // workgroup-uniform, before any barrier
+        prep_edges(Lf, Rf, H, W, T, (by - tiles_y) * gdx + bx);
         return;
     }
-    const int i0 = blockIdx.y * PTH;
-    const int x0 = blockIdx.x * PTW;
+    const int i0 = by * PTH;
+    const int x0 = bx * PTW;
     const int tid = threadIdx.x;
     // stage the tile + halo straight from the float images (coordinates clamped; out-of-image taps
     // are masked); this also is the float -> u8 conversion + domain check
     bool bad = false;
-    for (int e = tid; e < SR * SC; e += PNT) {
-        const int r = e / SC, c = e - r * SC;
+#pragma unroll 2
+    for (int e = tid; e < SR * PSC; e += PNT) {
+        const int r = e / PSC, c = e - r * PSC;
         int ii = i0 + r - 4, jj = x0 + c - 3;
         ii = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
         jj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
@@ -153,66 +215,24 @@ __global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, cons
     const int x = x0 + col;
     if (x >= W) return;
     constexpr int RPT = PTH / (PNT / PTW);                  // output rows per thread (consecutive)
-    const int row0 = (tid / PTW) * RPT;
-    // The thread's 7-byte window [col, col+6] of each of the RPT+8 staged rows it needs, as two dwords
-    // per image: three aligned LDS dwords shifted by col%4 bytes.  Bytes past col+6 are never used.
-    const int cw = col >> 2;
-    const unsigned sh = (unsigned)(col & 3);
-    uint32_t wl0[RPT + 8], wl1[RPT + 8], wr0[RPT + 8], wr1[RPT + 8];
-#pragma unroll
-    for (int r = 0; r < RPT + 8; r++) {
-        const uint32_t a0 = sLw[row0 + r][cw], a1 = sLw[row0 + r][cw + 1], a2 = sLw[row0 + r][cw + 2];
-        const uint32_t b0 = sRw[row0 + r][cw], b1 = sRw[row0 + r][cw + 1], b2 = sRw[row0 + r][cw + 2];
-        wl0[r] = __builtin_amdgcn_alignbyte(a1, a0, sh); wl1[r] = __builtin_amdgcn_alignbyte(a2, a1, sh);
-        wr0[r] = __builtin_amdgcn_alignbyte(b1, b0, sh); wr1[r] = __builtin_amdgcn_alignbyte(b2, b1, sh);
-    }
+    static_assert(RPT % PRR == 0, "");
     // column validity of the 7 taps, MSB = leftmost tap
     unsigned colbits = 0;
 #pragma unroll
     for (int c = 0; c < 7; c++) colbits |= (unsigned)(x + c - 3 >= 0 && x + c - 3 < W) << (6 - c);
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        const int i = i0 + row0 + rr;
-        if (i >= H) break;
-        // centre = byte 3 of the window of staged row rr+4
-        const int lc = (int)(wl0[rr + 4] >> 24), rc = (int)(wr0[rr + 4] >> 24);
-        T.u8[0][(size_t)i * W + x] = (uint8_t)lc;
-        T.u8[1][(size_t)i * W + x] = (uint8_t)rc;
-        // census word, MSB first over taps t = r*7 + c: bit = centre > neighbour = sign of
-        // (neighbour - centre), shifted in with one v_alignbit per tap.  Taps 0..30 fill the high word
-        // (bits 62..32), taps 31..62 the low word; every staged byte is readable, the raw bits are
-        // masked afterwards with the tap-validity word.
-        uint32_t clh = 0, cll = 0, crh = 0, crl = 0;
-        uint64_t m = 0;
-#pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int ii = i + r - 4;
-            if (ii >= 0 && ii < H) m |= (uint64_t)colbits << (56 - 7 * r);
-#pragma unroll
-            for (int c = 0; c < 7; c++) {
-                const int t = r * 7 + c;
-                const uint32_t wl = c < 4 ? wl0[rr + r] : wl1[rr + r];
-                const uint32_t wr = c < 4 ? wr0[rr + r] : wr1[rr + r];
-                const int dl = (int)((wl >> (8 * (c & 3))) & 0xffu) - lc;
-                const int dr = (int)((wr >> (8 * (c & 3))) & 0xffu) - rc;
-                if (t < 31) {
-                    clh = __builtin_amdgcn_alignbit(clh, (uint32_t)dl, 31);
-                    crh = __builtin_amdgcn_alignbit(crh, (uint32_t)dr, 31);
-                } else {
-                    cll = __builtin_amdgcn_alignbit(cll, (uint32_t)dl, 31);
-                    crl = __builtin_amdgcn_alignbit(crl, (uint32_t)dr, 31);
-                }
-            }
-        }
-        const uint64_t cl = (((uint64_t)clh << 32) | cll) & m;
-        const uint64_t cr = (((uint64_t)crh << 32) | crl) & m;
-        const size_t p = (size_t)i * W + x;
-        T.cenA[0][p] = cl;
-        T.cenA[1][p] = cr;
-        T.mask[p] = m;
-        if (x >= 3) T.cenX[0][(size_t)i * T.WX + x + 3] = cr;      // cenX_R index = xr + 3
-        if (x <= W - 4) T.cenX[1][(size_t)i * T.WX + x] = cl;      // cenX_L index = xl
+#pragma unroll 1
+    for (int s = 0; s < RPT / PRR; s++) {
+        const int row0 = (tid / PTW) * RPT + s * PRR;
+        prep_rows<0>(sLw, i0, row0, x, col, colbits, H, W, T);
+        __builtin_amdgcn_sched_barrier(0);                  // one image's window at a time in registers
+        prep_rows<1>(sRw, i0, row0, x, col, colbits, H, W, T);
     }
+}
+
+__global__ void __launch_bounds__(PNT) k_prep(const float *__restrict__ Lf, const float *__restrict__ Rf,
+                                              int H, int W, Tables T)
+{
+    prep_tile(Lf, Rf, H, W, T, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 template <int C> struct vecf { float v[C]; };          // C = 5..8 (D > 256): plain struct, the kernels there use the per-element paths
@@ -548,11 +568,11 @@ __device__ __forceinline__ void cost_fast_body(int H, int W, int Drt, const Tabl
 // that space: every XCD then streams its own region of the volumes instead of every eighth 48 KB piece
 // of the same region.  A store-only kernel with this mapping writes 10 % faster (6.9 vs 6.25 TB/s,
 // same box) than with chunks in dispatch order.  The grid is 1-D, padded to a multiple of 8.
-__device__ __forceinline__ bool chunk_of_block(int nbx, int H, int nviews, int &view, int &i, int &bx)
+__device__ __forceinline__ bool chunk_of_block(int nbx, int H, int nviews, int &view, int &i, int &bx, long b = -1)
 {
     const long nb = (long)nbx * H * nviews;
     const long per = (nb + 7) >> 3;
-    const long b = blockIdx.x;
+    if (b < 0) b = blockIdx.x;
     const long c = (b & 7) * per + (b >> 3);
     if (c >= nb) return false;
     const long rows = (long)nbx * H;
@@ -591,6 +611,64 @@ __global__ void __launch_bounds__(NT) k_cost_fast2(int H, int W, int D, Tables T
         unsigned long long *s = T.stamp + 4 * (size_t)blockIdx.x;
         s[0] = t0; s[1] = r0; s[2] = __builtin_amdgcn_s_memtime(); s[3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// k_cost_fast2 of pair n with the table workgroups of pair n + 1 spread through its grid (smt_adcensus_compute_batch):
+// one launch per pair on one stream -- no second stream, no events between the table and cost kernels -- with the
+// table workgroups (VALU / LDS work) running beside the store-bound cost workgroups instead of in front of them.
+// Workgroups come in groups of 8 (one per XCD, so a cost workgroup keeps the XCD of its chunk, chunk_of_block): after
+// every `every` cost groups one group of table workgroups, tile (p % ptx, p / ptx) of the table launch for the next
+// pair's images, writing the OTHER table set (Tn); what does not fit that pattern follows at the end of the grid.
+// fused_grid() is the host's side of the same arithmetic.  Measured against the two-stream form (tables of pair
+// n + 1 on an internal stream, two event edges per pair): DESIGN.md section 4.
+struct FusedGrid { int cgroups, pgroups, every, slots, groups; };
+__host__ __device__ inline FusedGrid fused_grid(int ncost, int nprep)
+{
+    FusedGrid f;
+    f.cgroups = ncost >> 3;                                  // ncost is a multiple of 8
+    f.pgroups = (nprep + 7) >> 3;
+    f.every = f.cgroups / (f.pgroups > 0 ? f.pgroups : 1);
+    if (f.every < 1) f.every = 1;
+    f.slots = f.cgroups / f.every;                           // table groups inside the cost range (>= pgroups unless every == 1)
+    f.groups = f.cgroups + (f.pgroups > f.slots ? f.pgroups : f.slots);
+    return f;
+}
+// group g of the fused grid -> (true, table group) or (false, cost group)
+__device__ __forceinline__ bool fused_decode(const FusedGrid &f, int g, int &idx)
+{
+    const int period = f.every + 1, inter = f.slots * period;
+    if (g < inter) {
+        const int q = g / period, r = g - q * period;
+        if (r == f.every) { idx = q; return true; }
+        idx = q * f.every + r;
+        return false;
+    }
+    const int g2 = g - inter, crest = f.cgroups - f.slots * f.every;
+    if (g2 < crest) { idx = f.slots * f.every + g2; return false; }
+    idx = f.slots + (g2 - crest);
+    return true;
+}
+
+template <int C, bool FULL, bool NTS = true>
+__global__ void __launch_bounds__(NT, 8) k_cost_fast2p(int H, int W, int D, Tables T, float *__restrict__ vol0,
+                                                       float *__restrict__ vol1, float *__restrict__ disp0,
+                                                       float *__restrict__ disp1, int nbx, int ncost, int nprep,
+                                                       const float *__restrict__ nL, const float *__restrict__ nR, Tables Tn,
+                                                       int ptx)
+{
+    static_assert(PNT == NT, "");
+    const FusedGrid f = fused_grid(ncost, nprep);
+    int idx;
+    const bool table = fused_decode(f, (int)(blockIdx.x >> 3), idx);   // workgroup-uniform
+    const int b = idx * 8 + (int)(blockIdx.x & 7);
+    if (table) {
+        if (b < nprep) prep_tile(nL, nR, H, W, Tn, b % ptx, b / ptx, ptx);
+        return;
+    }
+    int view, i, bx;
+    if (!chunk_of_block(nbx, H, 2, view, i, bx, b)) return;
+    if (view == 0) cost_fast_body<C, 0, FULL, NTS>(H, W, D, T, vol0, disp0, i, bx);
+    else cost_fast_body<C, 1, FULL, NTS>(H, W, D, T, vol1, disp1, i, bx);
 }
 
 // Store-only twin of k_cost_fast2<C, true>: the same grid, workgroup -> chunk order and streaming stores
@@ -797,7 +875,7 @@ static int place_volumes(smt_adcensus *h, bool allow_search)
 }
 
 template <int C, bool FULL>
-static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR);
+static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR, const float *nL = nullptr, const float *nR = nullptr);
 
 // Streaming (non-temporal) or ordinary stores for the volumes?  Streaming stores were worth 8-19 % on the
 // devices of round 1; on another device the store-only twin is 5 % FASTER with ordinary stores (DESIGN.md
@@ -1003,10 +1081,26 @@ static void launch_cost(smt_adcensus *h, int view0, int nviews, float *d0, float
 }
 
 template <int C, bool FULL>
-static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
+static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR, const float *nL, const float *nR)
 {
     const int nbx = (h->W + FTJ - 1) / FTJ;
     auto blocks = [&](int nviews) { return dim3((unsigned)(((long)nbx * h->H * nviews + 7) / 8 * 8)); };
+    if (views == SMT_VIEW_BOTH && nL) {
+        // this pair's cost workgroups + the next pair's table workgroups (into the other table set) in one launch
+        const int ncost = (int)blocks(2).x;
+        const int ptx = (h->W + PTW - 1) / PTW, pty = (h->H + PTH - 1) / PTH;
+        const int eb = (h->H + PNT / 16 - 1) / (PNT / 16);
+        const int nprep = ptx * (pty + (eb + ptx - 1) / ptx);
+        const unsigned grid = 8u * (unsigned)fused_grid(ncost, nprep).groups;
+        const Tables &Tn = h->TS[(h->n_pairs + 1) & 1];
+        if (h->plain_stores)
+            hipLaunchKernelGGL((k_cost_fast2p<C, FULL, false>), dim3(grid), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
+                               h->vol[0], h->vol[1], dL, dR, nbx, ncost, nprep, nL, nR, Tn, ptx);
+        else
+            hipLaunchKernelGGL((k_cost_fast2p<C, FULL, true>), dim3(grid), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T,
+                               h->vol[0], h->vol[1], dL, dR, nbx, ncost, nprep, nL, nR, Tn, ptx);
+        return;
+    }
     if (views == SMT_VIEW_BOTH) {
         if (h->plain_stores)
             hipLaunchKernelGGL((k_cost_fast2<C, FULL, false>), blocks(2), dim3(NT), 0, h->stream, h->H, h->W, h->D, h->T, h->vol[0],
@@ -1024,15 +1118,27 @@ static void launch_fast(smt_adcensus *h, int views, float *dL, float *dR)
                            h->vol[1], dR, nbx);
 }
 
-// One pair into table set (n & 1).  With overlap the table kernels run on the handle's internal
-// stream so that they overlap the previous pair's cost kernel on the caller's stream; event edges:
-//   cost_done[n-2] --> prep stream               (table set n&1 is free again)
-//   prep_done[n]   --> caller stream --> cost kernel(s) --> cost_done[n]
-// Overlap is only used for pairs b >= 1 of a batch (their inputs were already ordered behind the
-// caller's stream by pair 0): measured on MI355X it gives +18 % at 1242x375 D=256 and +2-3.5 % at 1920x1080
-// D=192 (the table kernels then take 0.09 instead of 0.04 ms, hidden behind a cost kernel that gets 1 % slower).
+// One pair into table set (n & 1).  Three schedules for the pairs of a batch:
+//   fused (default, both views through the register-window kernel): the table workgroups of pair n + 1 ride in the
+//     grid of pair n's cost kernel (k_cost_fast2p) -- one stream, one launch per pair, no events; `prepped` says this
+//     pair's tables were built that way, `nL / nR` are the next pair's images (null for the last pair of a batch);
+//   overlap (SMT_OVERLAP=1, and the schedule of single views / D > 256): the table kernels run on the handle's internal
+//     stream beside the previous pair's cost kernel on the caller's stream; event edges:
+//       cost_done[n-2] --> prep stream               (table set n&1 is free again)
+//       prep_done[n]   --> caller stream --> cost kernel(s) --> cost_done[n]
+//     only for pairs b >= 1 of a batch (their inputs were already ordered behind the caller's stream by pair 0);
+//   in order on the caller's stream (single pairs, the first pair of a batch, SMT_OVERLAP=0).
+// Measured on MI355X the overlap gives +18 % at 1242x375 D=256 and +2-3.5 % at 1920x1080 D=192 over the in-order form
+// (the table kernels then take 0.09 instead of 0.04 ms, hidden behind a cost kernel that gets 1 % slower); the fused
+// form against the overlap: DESIGN.md section 4.
+static bool fast_both_views(const smt_adcensus *h, int views)
+{
+    return views == SMT_VIEW_BOTH && !h->force_generic && (h->D + 63) / 64 <= 4;
+}
+
 static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int views, float *dL,
-                         float *dR, bool overlap)
+                         float *dR, bool overlap, bool prepped = false, const float *nL = nullptr,
+                         const float *nR = nullptr)
 {
     const int H = h->H, W = h->W, D = h->D;
     const int set = (int)(h->n_pairs & 1);
@@ -1044,7 +1150,7 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
     hipStream_t ps = overlap ? h->prep_stream : h->stream;
     if (overlap && h->n_pairs >= 2) SMT_HIP(hipStreamWaitEvent(ps, h->cost_done[set], 0));
     if (timed) (void)hipEventRecord(ev[0], ps);
-    {
+    if (!prepped) {
         // tile workgroups + the workgroups of the 13 border columns (16 rows each) in one launch
         const int tx = (W + PTW - 1) / PTW, ty = (H + PTH - 1) / PTH;
         const int eb = (H + PNT / 16 - 1) / (PNT / 16);
@@ -1076,19 +1182,20 @@ static int adcensus_pair(smt_adcensus *h, const float *L, const float *R, int vi
         }
     } else {
         switch (C * 2 + (full ? 1 : 0)) {
-        case 3: launch_fast<1, true>(h, views, dL, dR); break;
-        case 5: launch_fast<2, true>(h, views, dL, dR); break;
-        case 7: launch_fast<3, true>(h, views, dL, dR); break;
-        case 9: launch_fast<4, true>(h, views, dL, dR); break;
-        case 2: launch_fast<1, false>(h, views, dL, dR); break;
-        case 4: launch_fast<2, false>(h, views, dL, dR); break;
-        case 6: launch_fast<3, false>(h, views, dL, dR); break;
-        case 8: launch_fast<4, false>(h, views, dL, dR); break;
+        case 3: launch_fast<1, true>(h, views, dL, dR, nL, nR); break;
+        case 5: launch_fast<2, true>(h, views, dL, dR, nL, nR); break;
+        case 7: launch_fast<3, true>(h, views, dL, dR, nL, nR); break;
+        case 9: launch_fast<4, true>(h, views, dL, dR, nL, nR); break;
+        case 2: launch_fast<1, false>(h, views, dL, dR, nL, nR); break;
+        case 4: launch_fast<2, false>(h, views, dL, dR, nL, nR); break;
+        case 6: launch_fast<3, false>(h, views, dL, dR, nL, nR); break;
+        case 8: launch_fast<4, false>(h, views, dL, dR, nL, nR); break;
         default: return SMT_ERR_ARG;
         }
     }
     if (timed) { (void)hipEventRecord(ev[3], h->stream); h->n_timed++; }
-    SMT_HIP(hipEventRecord(h->cost_done[set], h->stream));
+    // the two-stream schedule waits on this before it reuses the table set; the fused one is ordered by its stream
+    if (!prepped && !nL) SMT_HIP(hipEventRecord(h->cost_done[set], h->stream));
     h->n_pairs++;
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1102,12 +1209,14 @@ SMT_API int smt_adcensus_compute(smt_adcensus *h, const float *L, const float *R
     return adcensus_pair(h, L, R, views, dispL, dispR, false);
 }
 
-static bool overlap_pays(const smt_adcensus *h)
+// schedule of the pairs b >= 1 of a batch: 0 in order, 1 two streams, 2 fused launches (adcensus_pair)
+static int batch_schedule(const smt_adcensus *h, int views)
 {
-    const char *env = getenv("SMT_OVERLAP");             // tuning hook: 0 / 1 forces the choice
-    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
-    (void)h;
-    return true;   // re-measured at the end of round 2: +18 % at 1242x375 D=256, +2-3.5 % at 1920x1080 D=192 (batches of 8)
+    const char *env = getenv("SMT_OVERLAP");             // tuning hook: 0 / 1 / 2 forces the choice
+    int want = 2;
+    if (env && env[0] >= '0' && env[0] <= '2' && env[1] == 0) want = env[0] - '0';
+    if (want == 2 && !fast_both_views(h, views)) want = 1;
+    return want;
 }
 
 SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const float *R, int pairs,
@@ -1116,15 +1225,17 @@ SMT_API int smt_adcensus_compute_batch(smt_adcensus *h, const float *L, const fl
     if (!h || !L || !R || pairs <= 0 || views < 1 || views > 3) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     const size_t N = (size_t)h->H * h->W;
-    const bool ov = pairs > 1 && overlap_pays(h);
-    if (ov) {
+    const int sched = pairs > 1 ? batch_schedule(h, views) : 0;
+    if (sched == 1) {
         // order the internal stream behind whatever produced the [pairs][H][W] inputs
         SMT_HIP(hipEventRecord(h->in_ready, h->stream));
         SMT_HIP(hipStreamWaitEvent(h->prep_stream, h->in_ready, 0));
     }
     for (int b = 0; b < pairs; b++) {
+        const bool more = sched == 2 && b + 1 < pairs;
         int rc = adcensus_pair(h, L + b * N, R + b * N, views, dispL ? dispL + b * N : nullptr,
-                               dispR ? dispR + b * N : nullptr, ov && b > 0);
+                               dispR ? dispR + b * N : nullptr, sched == 1 && b > 0, sched == 2 && b > 0,
+                               more ? L + (b + 1) * N : nullptr, more ? R + (b + 1) * N : nullptr);
         if (rc != SMT_OK) return rc;
     }
     return SMT_OK;
