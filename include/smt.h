@@ -273,7 +273,9 @@ int smt_crossarm_aggregate(smt_crossarm *h, const float *vol_in, float *vol_out,
                            float *disp);
 int smt_crossarm_status(smt_crossarm *h); /* synchronising; read-and-clear: reports rectangles that left the
                                              plane (or, order 2, were empty) since the previous status call */
-/* Test / tuning hook: which aggregation kernel runs.  12 (default) = 4x4 pixels per wave, every tap of the union of
+/* Test / tuning hook: which aggregation kernel runs.  13 (default) = 12 with the scalar side of a tap (byte offsets of
+ * its two flag rows, one "group has a member" bit per tile row) packed into one word by the vector classification of
+ * the batch; 12 = 4x4 pixels per wave, every tap of the union of
  * their rectangles loaded once and added under membership flags (v_pk_fma_f32, flag pairs in SGPRs), tile rows
  * without a member skipped, flag rows fetched one tap ahead, per-axis membership tables, and the four waves of a
  * workgroup (8 x 8 pixels) walking their common bounding box in lock-step, one s_barrier per 64 positions;

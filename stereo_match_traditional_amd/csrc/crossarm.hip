@@ -640,7 +640,7 @@ __device__ __forceinline__ i4v buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vo, un
 // pixel, 16-bit fields); the classification loop broadcasts them with v_readlane once per batch of 64
 // box positions, so no rectangle lives in SGPRs across the tap loop.
 template <int C, int ORDER, bool FULL, int QR, int SKIP, int TWS = 3>
-__global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3) : SKIP >= 4 ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3) : (SKIP == 4 || SKIP == 5) ? (C <= 3 ? 5 : 3) : (C <= 3 ? 6 : 4))) k_aggregate_multi(const float *__restrict__ vin, float *__restrict__ vout,
                                                         int H, int W, int D, const int *__restrict__ armL,
                                                         const int *__restrict__ armR, const int *__restrict__ armT,
                                                         const int *__restrict__ armB, float *__restrict__ disp,
@@ -675,11 +675,17 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
     // instruction's layout (register v of lane l = pixel 4 (l >> 4) + v, hypothesis 64 j + 4 n + r for accumulator
     // (j, r)), so this form has its own mean / store / WTA epilogue; D must be a multiple of 64.
     // All three are measured equal to or slower than SKIP == 3: kept as independent formulations.
+    // SKIP == 7 ("scalar word"): SKIP == 3 with the scalar side of a tap prepared by the vector classification of its
+    // batch: every position's lane packs, next to the membership mask, one word holding the byte offsets of the tap's
+    // two flag rows and one "group has a member" bit per group of four pixels.  The tap loop then reads that word with
+    // one v_readlane and spends s_and + s_lshr on the two row addresses and s_bitcmp1 + branch per group, instead of
+    // shift / mask / bit-field extract per row address and s_and + s_cmp + branch per group.
     constexpr bool MM = (SKIP == 6);
     constexpr bool MFMA = (SKIP == 4 || SKIP == 5);
     constexpr bool MSKIP = (SKIP == 5);
-    static_assert(SKIP <= 6 && (!MM || (QR == 2 && FULL)), "");
-    constexpr bool SYNC = (SKIP >= 3 && SKIP <= 5);      // 3 .. 5 walk in lock-step
+    constexpr bool SWORD = (SKIP == 7);
+    static_assert(SKIP <= 7 && (!MM || (QR == 2 && FULL)) && (!SWORD || QR == 2), "");
+    constexpr bool SYNC = (SKIP >= 3 && SKIP <= 5) || SWORD;   // 3 .. 5 and 7 walk in lock-step
     constexpr bool PREF = (SKIP >= 2);                   // flag rows fetched one tap ahead + per-axis tables
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -850,6 +856,13 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
     // (SKIP == 1 loads four flags per live group and waits for them on the spot).
     typedef float f8 __attribute__((ext_vector_type(8)));
     auto load_flags = [&](unsigned m, f8 (&F)[QR]) {
+        if constexpr (SWORD) {
+            // m = scalar word: bits 5..12 = 32 * (mask & 255), bits 21..28 = 32 * (mask >> 8): byte offsets of the rows
+            const char *mb8 = reinterpret_cast<const char *>(member);
+            F[0] = *reinterpret_cast<const f8 *>(mb8 + (m & 0x1fe0u));
+            F[QR - 1] = *reinterpret_cast<const f8 *>(mb8 + (m >> 16));
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < QR; h++) F[h] = *reinterpret_cast<const f8 *>(member + ((m >> (8 * h)) & 255u) * 8u);
     };
@@ -871,8 +884,14 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
                 for (int c = 0; c < C; c++)
                     acc[MFMA ? 0 : 4 * h + j][c] = __builtin_elementwise_fma(f2{x[c], x[c]}, fl, acc[MFMA ? 0 : 4 * h + j][c]);
             };
-            if (mb & 0x0fu) { pair(0); pair(1); }
-            if (mb & 0xf0u) { pair(2); pair(3); }
+            if constexpr (SWORD) {
+                // bits 0..3 of the scalar word: group g = pixels 4g .. 4g + 3 has a member (one s_bitcmp1 each)
+                if (__builtin_expect((m & (1u << (2 * h))) != 0, 1)) { pair(0); pair(1); }   // live bodies stay in line
+                if (__builtin_expect((m & (2u << (2 * h))) != 0, 1)) { pair(2); pair(3); }
+            } else {
+                if (mb & 0x0fu) { pair(0); pair(1); }
+                if (mb & 0xf0u) { pair(2); pair(3); }
+            }
         }
     };
 
@@ -943,6 +962,11 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
                 if (n >= total) mask = 0;
             }
             if (SYNC && ub) mask = 0;                    // reference-undefined tile: every pixel goes to the plain walk below
+            unsigned sword = 0;
+            if constexpr (SWORD)
+                sword = (unsigned)((mask & 0x000fu) != 0) | ((unsigned)((mask & 0x00f0u) != 0) << 1) |
+                        ((unsigned)((mask & 0x0f00u) != 0) << 2) | ((unsigned)((mask & 0xf000u) != 0) << 3) |
+                        ((mask & 255u) << 5) | ((mask >> 8) << 21);
             const unsigned offs = (unsigned)(p0 + o * so + t * si) * (unsigned)(D * 4);
             unsigned long long live = __ballot(mask != 0);
             // groups of union taps: indices, then all loads, then the in-order adds.  A short last
@@ -964,7 +988,7 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
                     const bool valid = !PAD || live != 0;
                     if (valid) last = next();
                     u[k] = last;
-                    m[k] = valid ? (unsigned)__builtin_amdgcn_readlane((int)mask, last) : 0u;
+                    m[k] = valid ? (unsigned)__builtin_amdgcn_readlane((int)(SWORD ? sword : mask), last) : 0u;
                 }
 #pragma unroll
                 for (int k = 0; k < GG; k++) ld((unsigned)__builtin_amdgcn_readlane((int)offs, u[k]), x[k]);
@@ -1336,7 +1360,7 @@ SMT_API int smt_crossarm_create(int H, int W, int D, const smt_crossarm_params *
     smt_crossarm *h = new (std::nothrow) smt_crossarm();
     if (!h) return SMT_ERR_ALLOC;
     h->device = smt_current_device();
-    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 12;
+    h->H = H; h->W = W; h->D = D; h->strip_w = 16; h->strip_w8 = 8; h->variant = 13;
     {
         // default: no limit (6 waves per SIMD from the register count), see smt_crossarm_set_occupancy; SMT_AGG_WAVES overrides
         static const int env_waves = [] { const char *e = getenv("SMT_AGG_WAVES"); return e ? atoi(e) : -1; }();
@@ -1643,7 +1667,8 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     if (!h->have_arms) return SMT_ERR_STATE;
     // variant: 12 = 4x4 pixels per wave sharing the taps of the union of their rectangles, membership flags,
     // groups of 4 pixels (= tile rows) without a member skipped, flag rows prefetched, per-axis membership tables, the
-    // four waves of a workgroup (8 x 8 pixels) in lock-step (default); 7 = the same with 2x8 tiles (round 2's default);
+    // four waves of a workgroup (8 x 8 pixels) in lock-step; 13 = 12 with the tap's flag-row offsets and group bits
+    // packed into one word by the batch classification (default); 7 = 12 with 2x8 tiles (round 2's default);
     // 6 = 7 free-running; 4 = 6 with flags per live group and pixel-by-pixel classification; 5 = 4 without the skip;
     // 3 = 1x8 pixels, no skip; 8 / 9 = 7 with the flagged accumulate on the matrix pipe (v_mfma_f32_4x4x1: every
     // group / live groups only), 11 = 9 with 4x4 tiles, 10 = four taps per v_mfma_f32_16x16x4 (4x4 tiles, free-running);
@@ -1667,6 +1692,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
     else if (variant == 10) { if (order == 0) launch_agg_multi<0, 2, 6, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 6, 2>(h, vin, vout, disp); }
     else if (variant == 11) { if (order == 0) launch_agg_multi<0, 2, 5, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 5, 2>(h, vin, vout, disp); }
     else if (variant == 12) { if (order == 0) launch_agg_multi<0, 2, 3, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 3, 2>(h, vin, vout, disp); }
+    else if (variant == 13) { if (order == 0) launch_agg_multi<0, 2, 7, 2>(h, vin, vout, disp); else launch_agg_multi<1, 2, 7, 2>(h, vin, vout, disp); }
     else { if (order == 0) launch_agg_pipe<0>(h, vin, vout, disp); else launch_agg_pipe<1>(h, vin, vout, disp); }
     SMT_LAUNCH_CHECK();
     return SMT_OK;
@@ -1674,7 +1700,7 @@ SMT_API int smt_crossarm_aggregate(smt_crossarm *h, const float *vin, float *vou
 
 SMT_API int smt_crossarm_set_variant(smt_crossarm *h, int variant)
 {
-    if (!h || variant < 0 || variant > 12) return SMT_ERR_ARG;
+    if (!h || variant < 0 || variant > 13) return SMT_ERR_ARG;
     smt_dev_guard dev_guard(h->device);
     h->variant = variant;
     // the lock-step kernel wants its four waves stacked vertically (8 columns x 8 rows per workgroup: the

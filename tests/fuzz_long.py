@@ -1,5 +1,5 @@
 """Long randomized parity run (not collected by pytest): AD-Census both views + WTA (D up to 512), every union-sharing
-aggregation kernel (variants 3-12, the matrix-pipe forms included), SAD (both formulations) and ASW (all formulations)
+aggregation kernel (variants 3-13, the matrix-pipe forms included), SAD (both formulations) and ASW (all formulations)
 against the oracle at random shapes for ~150 s.
 usage on the GPU box: python tests/fuzz_long.py [seed] [seconds]
 (last run, round 3: seed 4242, 240 s: 2 538 cases of each of the four families, all bit-exact)"""
@@ -45,7 +45,7 @@ while time.time() - t0 < budget:
     ref, oob = O.aggregate_rect(vol, arms, order)
     ca = smt.CrossArmAggregation().Initialize(H, W, tau, D, DEV, style="adcensus" if chain else "cblsm", quirks=QUIRK_FIX_RIGHT_ARM_STRIDE)
     ca.ComputeArmLengths(T(img))
-    for variant in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+    for variant in (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
         ca.set_variant(variant)
         if variant < 7: ca.set_strip_width(int(rng.choice([8, 16, 32, 64])))
         out = torch.empty((H, W, D), device=DEV); disp = torch.empty((H, W), device=DEV)

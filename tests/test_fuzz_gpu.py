@@ -64,7 +64,7 @@ def test_fuzz_arms_and_aggregation(smt, O):
         from stereo_match_traditional_amd._lib import QUIRK_FIX_RIGHT_ARM_STRIDE
         ca = smt.CrossArmAggregation().Initialize(H, W, tau, D, DEV, style="adcensus" if chain else "cblsm",
                                                   quirks=QUIRK_FIX_RIGHT_ARM_STRIDE)
-        ca.set_variant(it % 13)
+        ca.set_variant(it % 14)
         ca.ComputeArmLengths(T(img))
         for g, r in zip(ca.arm_maps(), arms):
             assert np.array_equal(g.cpu().numpy(), r), (H, W, tau, chain)

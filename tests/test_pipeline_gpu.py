@@ -95,7 +95,7 @@ AGG_CASES = [(72, 160, 16, "synth", 3), (64, 150, 64, "smooth", 5), (72, 160, 10
 AGG_CASES += [(70, 155, 60, "smooth", 12), (66, 149, 7, "synth", 13)]   # W % 16 != 0, D % 4 != 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("H,W,D,kind,seed", AGG_CASES)
 @pytest.mark.parametrize("order", [0, 1])
 def test_aggregation(smt, O, H, W, D, kind, seed, order, variant):
@@ -139,7 +139,7 @@ def test_aggregation_non_finite_inputs(smt, O, order):
     ref, oob = O.aggregate_rect(vol, arms, order)
     assert oob == 0
     outs = []
-    for variant in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+    for variant in (1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
         ca = smt.CrossArmAggregation().Initialize(H, W, 30 if order == 0 else 25, D, DEV,
                                                   style="adcensus" if order == 0 else "cblsm")
         ca.set_variant(variant)
@@ -333,7 +333,7 @@ def test_config3_full_size_properties(smt):
     assert no2 + nm2 == no1 + nm1
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_cblsm_portrait_image(smt, O, variant):
     """CBLSM-style arms have no stride bug, so portrait images are defined: arms + row-major
     aggregation (costAggregationV5) on a 96x61 image, D not a multiple of 4."""
@@ -357,7 +357,7 @@ def test_cblsm_portrait_image(smt, O, variant):
     ca.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_aggregation_out_of_plane_taps_contribute_nothing(smt, O, variant):
     """Rectangles that leave the plane are reference UB (status says so); what every kernel
     variant then computes is documented: the sum over the in-plane taps, divided by the full
@@ -461,7 +461,7 @@ def test_aggregation_variants_agree_above_2gib(smt):
     ca.AggregationVertical(vol, ref)
     ca.status()
     out = torch.empty((H, W, D), device=DEV)
-    for variant in (12, 11, 10, 9, 8, 7, 6, 4, 3, 0):
+    for variant in (13, 12, 11, 10, 9, 8, 7, 6, 4, 3, 0):
         out.zero_()
         ca.set_variant(variant)
         ca.AggregationVertical(vol, out)
@@ -487,7 +487,7 @@ def test_aggregation_mean_is_ieee_division_on_extreme_values(smt):
     ca.set_variant(1)
     ca.AggregationVertical(vol, ref)
     out = torch.empty((H, W, D), device=DEV)
-    for variant in (12, 11, 10, 9, 8, 7, 6, 4, 3, 5):
+    for variant in (13, 12, 11, 10, 9, 8, 7, 6, 4, 3, 5):
         out.zero_()
         ca.set_variant(variant)
         ca.AggregationVertical(vol, out)

@@ -20,7 +20,7 @@ adc.ComputeBoth()
 out = torch.empty((H, W, D), device=DEV)
 res = {"tag": sys.argv[1] if len(sys.argv) > 1 else "", "lib": os.environ.get("SMT_HIP_LIB", "default"),
        "SMT_AGG_WAVES": os.environ.get("SMT_AGG_WAVES")}
-variants = [int(v) for v in os.environ.get("AGG_VARIANTS", "7").split(",")]
+variants = [int(v) for v in os.environ.get("AGG_VARIANTS", "13").split(",")]
 for name, img, vol in (("left", Lu, adc.GetPtrLeft()), ("right", Ru, adc.GetPtrRight())):
     ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
     ca.ComputeArmLengths(img)

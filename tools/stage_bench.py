@@ -55,10 +55,10 @@ def pipeline(H, W, D, seed, noise, reps):
     aggR = torch.empty((H, W, D), device=DEV)
     rL, rR, rT, rB = [a.float() for a in caR.arm_maps()]
     res["mean_rect_area_right"] = float(((rL + rR + 1) * (rT + rB + 1)).mean())
-    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+    for v in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
         caL.set_variant(v)
         res[f"aggregate_L_variant{v}_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
-    caL.set_variant(12)                                   # the default: 4x4 tiles, lock-step workgroups
+    caL.set_variant(13)                                   # the default: 4x4 tiles, lock-step workgroups, scalar word
     res["aggregate_L_ms"] = timed(lambda: caL.AggregationVertical(adc.GetPtrLeft(), aggL), max(1, reps // 4))
     res["aggregate_R_ms"] = timed(lambda: caR.AggregationVertical(adc.GetPtrRight(), aggR, dR), max(1, reps // 4))
     caL.status()
