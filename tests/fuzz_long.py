@@ -2,7 +2,8 @@
 aggregation kernel (variants 3-13, the matrix-pipe forms included), SAD (both formulations) and ASW (all formulations)
 against the oracle at random shapes for ~150 s.
 usage on the GPU box: python tests/fuzz_long.py [seed] [seconds]
-(last run, round 3: seed 4242, 240 s: 2 538 cases of each of the four families, all bit-exact)"""
+(last runs, round 3: seed 4242, 240 s: 2 538 cases of each of the four families; seed 777, 300 s with the batch entry under
+random schedules and aggregation variant 13: 1 202 cases of each; all bit-exact)"""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,6 +35,20 @@ while time.time() - t0 < budget:
     assert np.array_equal(bits(adc.GetPtrLeft().cpu().numpy()), bits(vl)), ("adcL", H, W, D)
     assert np.array_equal(bits(adc.GetPtrRight().cpu().numpy()), bits(vr)), ("adcR", H, W, D)
     assert np.array_equal(dl.cpu().numpy(), O.wta(vl)) and np.array_equal(dr.cpu().numpy(), O.wta(vr)), ("wta", H, W, D)
+    # the same handle through the batch entry, 2..4 pairs (pair 0 = the pair above, the others its row-shifted / swapped
+    # siblings), under a random schedule: in order, tables on the internal stream, tables inside the previous cost launch
+    B = int(rng.integers(2, 5))
+    Ls = [L] + [np.roll(L, b, axis=0) if b % 2 else R for b in range(1, B)]
+    Rs = [R] + [np.roll(R, b, axis=0) if b % 2 else L for b in range(1, B)]
+    os.environ["SMT_OVERLAP"] = str(int(rng.integers(0, 3)))
+    dlb = torch.empty((B, H, W), device=DEV); drb = torch.empty((B, H, W), device=DEV)
+    adc.ComputeBatch(T(np.stack(Ls)), T(np.stack(Rs)), dlb, drb)
+    os.environ.pop("SMT_OVERLAP")
+    for b in range(1, B):
+        wl = O.adcensus_view(Ls[b], Rs[b], D, 10.0, 30.0, 0); wr = O.adcensus_view(Ls[b], Rs[b], D, 10.0, 30.0, 1)
+        assert np.array_equal(dlb[b].cpu().numpy(), O.wta(wl)) and np.array_equal(drb[b].cpu().numpy(), O.wta(wr)), ("batch wta", H, W, D, b)
+    assert np.array_equal(dlb[0].cpu().numpy(), O.wta(vl)) and np.array_equal(drb[0].cpu().numpy(), O.wta(vr)), ("batch wta 0", H, W, D)
+    assert np.array_equal(bits(adc.GetPtrLeft().cpu().numpy()), bits(wl)) and np.array_equal(bits(adc.GetPtrRight().cpu().numpy()), bits(wr)), ("batch vol", H, W, D)
     adc.close(); n_adc += 1
     # ---- aggregation, new variants
     H, W = int(rng.integers(2, 50)), int(rng.integers(2, 140))
