@@ -496,6 +496,39 @@ def test_aggregation_mean_is_ieee_division_on_extreme_values(smt):
     ca.close()
 
 
+@pytest.mark.parametrize("seed,max_arm", [(1, 6), (2, 20), (3, 34), (4, 60)])
+def test_aggregation_fast_quotient_is_the_ieee_quotient(smt, seed, max_arm):
+    """Variant 13 divides by the rectangle area with rcp + multiply + two FMAs where every value of a pixel lies in
+    [2^-60, 2^61) and the area is at most 8191 (crossarm.hip, `finish`); everywhere else, and in variant 1, the IEEE
+    division runs.  Random rectangle areas from 1 to (2*max_arm+1)^2 (above 8191 with max_arm = 60: the slow path),
+    random mantissas with exponents from -75 to 75 and both signs, a plane of zeros: bit-identical to variant 1."""
+    H, W, D = 96, 130, 64
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    ii = torch.arange(H, device=DEV)[:, None].expand(H, W); jj = torch.arange(W, device=DEV)[None, :].expand(H, W)
+    def arms(limit):
+        a = torch.randint(0, max_arm + 1, (H, W), device=DEV, generator=g)
+        return torch.minimum(a, limit).to(torch.int32).contiguous()
+    aL, aR, aT, aB = arms(jj), arms(W - 1 - jj), arms(ii), arms(H - 1 - ii)
+    expo = torch.randint(-75, 76, (H, W, D), device=DEV, generator=g).float()
+    sign = torch.randint(0, 2, (H, W, D), device=DEV, generator=g).float() * 2 - 1
+    vol = (1 + torch.rand((H, W, D), device=DEV, generator=g)) * torch.exp2(expo) * sign
+    # per-plane exponent for half of the planes (sums then stay near one magnitude), one plane of zeros
+    plane = torch.exp2(torch.randint(-70, 70, (D,), device=DEV, generator=g).float())
+    vol[:, :, ::2] = (1 + torch.rand((H, W, D // 2), device=DEV, generator=g)) * plane[::2]
+    vol[:, :, 7] = 0.0
+    ca = smt.CrossArmAggregation().Initialize(H, W, 30, D, DEV)
+    ca.load_arm_maps(aL, aR, aT, aB)
+    ref = torch.empty((H, W, D), device=DEV); out = torch.empty((H, W, D), device=DEV)
+    for order, fn in ((0, ca.AggregationVertical), (1, ca.costAggregationV5)):
+        ca.set_variant(1); fn(vol, ref)
+        ca.set_variant(13); out.zero_(); fn(vol, out)
+        ca.status()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), order
+    area = ((aL + aR + 1) * (aT + aB + 1))
+    assert int(area.min()) < 64 and (int(area.max()) > 8191) == (max_arm == 60)
+    ca.close()
+
+
 def test_wta_nan_semantics(smt, O):
     """smt_wta on arbitrary caller volumes: the reference's `if (cost > value)` (CrossArm.cpp:44-52,
     ScanlineOptimizer.h:51-59) is false for every comparison with a NaN, so a NaN never wins and a NaN at
