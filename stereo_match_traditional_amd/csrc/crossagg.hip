@@ -340,10 +340,19 @@ __global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, 
             }
         }
         float *o = dst + p * D + dl;
-        const float n = FINAL ? (float)cnt[p] : 1.0f;
+        if constexpr (FINAL) {
+            // cost / count (cross_aggregator.cpp:389, float over uint16): the correctly rounded quotient without the division sequence
+            // (wave_quotient, smt_common.h; k_ca_pass keeps the IEEE division as the independent formulation)
+            float qv[C];
+            wave_quotient<C, FULL>(a, (float)cnt[p], dl, D, qv);
 #pragma unroll
-        for (int k = 0; k < C; k++)
-            if (FULL || dl + k < D) o[k] = FINAL ? a[k] / n : a[k];
+            for (int k = 0; k < C; k++)
+                if (FULL || dl + k < D) o[k] = qv[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+                if (FULL || dl + k < D) o[k] = a[k];
+        }
     }
 }
 

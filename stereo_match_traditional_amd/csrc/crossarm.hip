@@ -1088,37 +1088,11 @@ __global__ void __launch_bounds__(NT, (SKIP == 6 ? (C <= 2 ? 5 : C == 3 ? 4 : 3)
         const int p = p0 + (q >> TWS) * W + (q & (QC - 1));
         float *dst = vout + (size_t)p * D + dl;
         float mean[C];
-        // SKIP == 7: the correctly rounded quotient in 3 vector instructions per value instead of the 11 of the IEEE
-        // division sequence (48 divisions per wave are 8 % of the kernel's vector instructions).  With b = fc an integer
-        // <= 8191, r = v_rcp_f32(b) (error <= 1 ulp; 2 would do), q0 = RN(a r), rem = fma(-q0, b, a), q = fma(rem, r, q0):
-        //  * |q0 - a/b| < 3 ulp, so rem = a - q0 b is a multiple of ulp(q0) below 2^16 of them: exact in the fma;
-        //  * q0 + rem r = a/b + (a/b - q0) e1 with |e1| <= 2^-23: within 2^-21 ulp of the true quotient;
-        //  * a/b is never closer than 2^-14 ulp to a rounding boundary (a - b m is a non-zero multiple of half an ulp of the
-        //    quotient for every midpoint m -- b m has 25 significant bits or more, a has 24 -- and b < 2^13),
-        // so the final rounding is the rounding of a/b.  Holds while nothing leaves the normal range: every value of the
-        // pixel must lie in [2^-60, 2^61) (zeros, denormals, infinities and NaNs take the division), checked per pixel.
-        bool fast = false;
-        if constexpr (SWORD) {
-            if (fc <= 8191.0f) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < C; k++) {
-                    const unsigned t = (__float_as_uint(a[k]) << 1) - (67u << 24);       // biased exponent - 67, sign dropped
-                    ok = ok && ((!FULL && dl + k >= D) || t < (121u << 24));
-                }
-                fast = __ballot(!ok) == 0;
-            }
-        }
-        if (fast) {
-            float r = __builtin_amdgcn_rcpf(fc), fv = fc;
-            asm volatile("" : "+v"(r), "+v"(fv));          // vector operands: an SGPR multiplier halves the FMA rate
-#pragma unroll
-            for (int k = 0; k < C; k++) {
-                const float q0 = a[k] * r;
-                const float rem = __builtin_fmaf(-q0, fv, a[k]);
-                mean[k] = __builtin_fmaf(rem, r, q0);
-            }
-        } else {
+        // SKIP == 7: the correctly rounded quotient in 3 vector instructions per value (wave_quotient, smt_common.h) where
+        // the other variants run the IEEE division sequence -- 48 divisions per wave are 8 % of this kernel's vector
+        // instructions
+        if constexpr (SWORD) wave_quotient<C, FULL>(a, fc, dl, D, mean);
+        else {
 #pragma unroll
             for (int k = 0; k < C; k++) mean[k] = a[k] / fc;
         }

@@ -499,8 +499,8 @@ def test_aggregation_mean_is_ieee_division_on_extreme_values(smt):
 @pytest.mark.parametrize("seed,max_arm", [(1, 6), (2, 20), (3, 34), (4, 60)])
 def test_aggregation_fast_quotient_is_the_ieee_quotient(smt, seed, max_arm):
     """Variant 13 divides by the rectangle area with rcp + multiply + two FMAs where every value of a pixel lies in
-    [2^-60, 2^61) and the area is at most 8191 (crossarm.hip, `finish`); everywhere else, and in variant 1, the IEEE
-    division runs.  Random rectangle areas from 1 to (2*max_arm+1)^2 (above 8191 with max_arm = 60: the slow path),
+    [2^-60, 2^61) and the area is at most 65535 (wave_quotient, smt_common.h); everywhere else, and in variant 1, the IEEE
+    division runs.  Random rectangle areas from 1 to (2*max_arm+1)^2 (up to 12 480 on this image),
     random mantissas with exponents from -75 to 75 and both signs, a plane of zeros: bit-identical to variant 1."""
     H, W, D = 96, 130, 64
     g = torch.Generator(device=DEV).manual_seed(seed)
