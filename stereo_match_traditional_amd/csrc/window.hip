@@ -429,9 +429,23 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 4 * side * RW; e += NCP * 64) {
-        const int sft = e / (side * RW), rem = e - sft * (side * RW), r = rem / RW, w = rem - r * RW;
-        s_R[ncc_copy_off<K>(sft, CS) + r * RW + w] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
+    // K == 1 (D <= 64): the four copies interleaved dword by dword, E[r][4 w + s] = the dword at byte offset 4 w + s of
+    // row r.  A half-wave's lanes then read the dwords at 32 consecutive byte offsets o = c - lane: 32 consecutive LDS
+    // dwords, conflict-free for every pixel.  With the copies apart (below) a lane whose byte offset crosses a dword
+    // boundary of the row reads one word lower than its neighbours, which puts two lanes of a half-wave on one bank for
+    // three pixels in four (PMC: 26 % of the LDS cycles at D = 64 were conflict cycles).  For K > 1 the groups sit 4K
+    // bytes apart and the interleaved form would fold them onto each other: the separate copies stay.
+    constexpr bool EL = (K == 1);
+    if constexpr (EL) {
+        for (int e = threadIdx.x; e < 4 * side * RW; e += NCP * 64) {
+            const int sft = e & 3, rw = e >> 2, r = rw / RW, w = rw - r * RW;
+            s_R[e] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
+        }
+    } else {
+        for (int e = threadIdx.x; e < 4 * side * RW; e += NCP * 64) {
+            const int sft = e / (side * RW), rem = e - sft * (side * RW), r = rem / RW, w = rem - r * RW;
+            s_R[ncc_copy_off<K>(sft, CS) + r * RW + w] = __builtin_amdgcn_alignbyte(s_raw[r * (RW + 1) + w + 1], s_raw[r * (RW + 1) + w], (unsigned)sft);
+        }
     }
     __syncthreads();
     if (!live) return;
@@ -439,18 +453,23 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
     // Hypotheses of a lane: d = 4K * (lane / 4) + 4k + lane % 4, k = 0..K-1.  Slot k at tap group g then needs the
     // dword 4k bytes before slot 0's, i.e. the dword slot 0 needs at group g - k: one LDS read per row position
     // serves every slot (G + K - 1 reads per window row instead of G * K).
+    // K > 1 and D <= 64 K - 3: the hypotheses of the wave start at d = ((j - win - xlo) & 3) - 3 (-3 .. 0) instead of 0, so
+    // that the four lanes of a group read the four copies at ONE word index: with the set starting at 0 a lane whose
+    // byte offset crosses a dword boundary reads one word lower than its neighbours and lands on the bank of another
+    // group's lane (28 % of the LDS cycles at D = 200 were conflict cycles).  Lanes with d < 0 are idle.
     const int grp = lane >> 2, rr = lane & 3;
-    const int d0 = 4 * K * grp + rr;
+    const int sh = (K > 1 && D <= 64 * K - 3) ? ((j - win - xlo) & 3) - 3 : 0;
+    const int d0 = 4 * K * grp + rr + sh;
     unsigned sab[K];
 #pragma unroll
     for (int k = 0; k < K; k++) sab[k] = 0u;
-    const int o = (j - win - d0) - xlo;                   // >= 4K - 4: xlo <= j0 - win - (64K - 1), d0 <= 60K + 3
-    const uint32_t *pb = s_R + ncc_copy_off<K>(o & 3, CS) + (o >> 2) - (K - 1);
+    const int o = (j - win - d0) - xlo;                   // >= 4K - 4: xlo <= j0 - win - (64K - 1), d0 <= 60K + 3; at most 64K + 20
+    const uint32_t *pb = EL ? s_R + o : s_R + ncc_copy_off<K>(o & 3, CS) + (o >> 2) - (K - 1);
     const uint32_t *ap = s_A + wv * side * G;
     for (int r = 0; r < side; r++) {
         uint32_t bv[G + K - 1];
 #pragma unroll
-        for (int t = 0; t < G + K - 1; t++) bv[t] = lds_u32(pb + t);
+        for (int t = 0; t < G + K - 1; t++) bv[t] = lds_u32(pb + (EL ? 4 * t : t));
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const uint32_t a = lds_u32(ap + g);           // one address for the whole wave: a broadcast read
@@ -458,7 +477,7 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
             for (int k = 0; k < K; k++) sab[k] = __builtin_amdgcn_udot4(a, bv[g - k + K - 1], sab[k], false);
         }
         ap += G;
-        pb += RW;
+        pb += EL ? 4 * RW : RW;
     }
     // cost per hypothesis (float64)
     const double n = (double)(side * side);
@@ -469,7 +488,7 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int d = d0 + 4 * k;
-        const bool act = d < D;
+        const bool act = d >= 0 && d < D;
         if (act && j - win - d >= 0) {
             const size_t q = (size_t)p - d;
             const double num = n * (double)sab[k] - sa * (double)sumR[q];
@@ -477,7 +496,7 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
         } else c[k] = 255.0;                              // `invalid` 0xff, NCC.h:88
         if (cost_out && act) cost_out[(size_t)p * D + d] = c[k];
         const bool isn = c[k] != c[k];
-        if (k == 0) poison = __builtin_amdgcn_readfirstlane((int)isn) != 0;   // lane 0, slot 0 is d = 0
+        if (k == 0) poison = __ballot(isn && d == 0) != 0;   // d = 0 sits in slot 0 of one of the first four lanes
         v[k] = (act && !isn) ? (float)c[k] : -INFINITY;
     }
     // WinTakeAll.  m before step d = max over e < d of (float)c[e] with NaNs skipped (a NaN at d = 0 makes every test
@@ -504,7 +523,7 @@ __global__ void __launch_bounds__(NCP * 64) k_ncc2(const uint8_t *__restrict__ L
     for (int k = 0; k < K; k++) {
         const int d = d0 + 4 * k;
         const float m = fmaxf(before, exq[k]);
-        if (d < D && (double)m < c[k]) key = (unsigned)d + 1u;    // d grows with k
+        if (d >= 0 && d < D && (double)m < c[k]) key = (unsigned)d + 1u;    // d grows with k
     }
     const unsigned kmax = ~wave_min_u32(~key);            // the last winner
     if (lane == 0) disp[p] = (poison || kmax == 0u) ? 0 : (int)(kmax - 1u);
@@ -1079,7 +1098,7 @@ SMT_API int smt_ncc(const uint8_t *L, const uint8_t *R, int H, int W, int D, int
             hipLaunchKernelGGL(k_ncc_stats, dim3((Wi + 63) / 64, (Hi + NCT - 1) / NCT, 2), dim3(256), shm1, st, L, R, H, W, winSize,
                                sums, roots, sums + N, roots + N);
             const int K = (D + 63) / 64, G = (side + 3) / 4;
-            const int RW = 16 * K + G + 4, CS = (side * RW + 31) / 32 * 32 + 32;   // + 32: room for the copies' bank offsets
+            const int RW = 16 * K + G + 5, CS = (side * RW + 31) / 32 * 32 + 32;   // + 32: room for the copies' bank offsets
             const size_t shm2 = ((size_t)4 * CS + (size_t)side * (RW + 1) + (size_t)NCP * side * G) * 4;
             const dim3 grid((Wi + NCP - 1) / NCP, Hi);
             int rc;
