@@ -133,27 +133,28 @@ __global__ void __launch_bounds__(NT) k_sad(const uint8_t *__restrict__ Lp, cons
 // Second formulation (default for windows of side >= 4): k_sad above is bound by its own global-load latency (one
 // wave per pixel, ten unaligned dword loads per lane and pixel at 5x5; 0.8 % of the v_sad_u8 rate at config 1).
 // Here a workgroup owns STP consecutive pixels of a row and stages, once, the `side` rows of the anchor image over
-// its pixels and of the other image over every window position its hypotheses can touch -- each as FOUR byte-shifted
-// dword arrays (copy s, word j = bytes 4j + s .. 4j + s + 3), so that the four bytes at any byte address A are the
-// aligned dword copy[A & 3][A >> 2].  The tap loop is then LDS reads + v_sad_u8 only: per window row and group of four
-// columns one uniform (broadcast) read of the anchor dword and one read per hypothesis slot, lanes with consecutive d
-// hitting the four copies in turn (copy strides are 8 banks apart: conflict-free).  Sums, masks and the selection rules
-// are those of k_sad; the two are compared bit for bit in the tests.
+// its pixels and of the other image over every window position its hypotheses can touch -- each row expanded to one
+// dword per BYTE offset (E[A] = bytes A .. A + 3: the four byte-shifted copies of the row interleaved dword by dword),
+// so that the four bytes at any byte address A are the aligned dword E[A].  The tap loop is then LDS reads + v_sad_u8
+// only: per window row and group of four columns one uniform (broadcast) read of the anchor dword and one read per
+// hypothesis slot; lanes with consecutive d read consecutive dwords, conflict-free whatever the pixel.  (With the four
+// copies kept apart, 8 banks from each other, a lane whose byte offset crosses a dword boundary reads one word lower
+// than its neighbours and shares a bank with another lane for three pixels in four -- the NCC kernel had the same flaw.)
+// Sums, masks and the selection rules are those of k_sad; the two are compared bit for bit in the tests.
 constexpr int STP = 32;                                   // pixels per workgroup (8 per wave)
 
 template <int K>
 __global__ void __launch_bounds__(NT) k_sad2(const uint8_t *__restrict__ Lp, const uint8_t *__restrict__ Rp, int H, int W,
                                              int D, int w, int view, int32_t *__restrict__ disp, int ALW, int OLW)
 {
-    extern __shared__ unsigned s_sad[];
+    extern __shared__ __attribute__((aligned(16))) unsigned s_sad[];
     const int side = 2 * w + 1, Wp = W + 2 * w;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int io = blockIdx.y, jo0 = blockIdx.x * STP;
-    // ALW / OLW: dwords per copy row of the anchor / other image, both = 8 (mod 32) so that the four copies of a row
-    // start 8 banks apart
-    unsigned *s_a = s_sad;                                 // [side][4][ALW]
-    unsigned *s_o = s_sad + (size_t)side * 4 * ALW;        // [side][4][OLW]
+    // ALW / OLW: dword columns staged per row of the anchor / other image (4 expanded dwords each)
+    unsigned *s_a = s_sad;                                 // [side][4 * ALW]
+    unsigned *s_o = s_sad + (size_t)side * 4 * ALW;        // [side][4 * OLW]
     const uint8_t *Aimg = (view == 0 ? Lp : Rp) + (size_t)io * Wp;
     const uint8_t *Bimg = (view == 0 ? Rp : Lp) + (size_t)io * Wp;
     // first byte column staged of the other image: view 0: jo0 - (64 K - 1) .. ; view 1: jo0 ..
@@ -181,11 +182,9 @@ __global__ void __launch_bounds__(NT) k_sad2(const uint8_t *__restrict__ Lp, con
                     hi |= (unsigned)row[xb] << (8 * b);
                 }
             }
-            unsigned *d = dst + (size_t)r * 4 * LW + j;
-            d[0] = lo;
-            d[LW] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-            d[2 * LW] = __builtin_amdgcn_alignbyte(hi, lo, 2);
-            d[3 * LW] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u4v *>(dst + (size_t)r * 4 * LW + 4 * j) =     // one 16-byte store: E[4j .. 4j + 3]
+                u4v{lo, __builtin_amdgcn_alignbyte(hi, lo, 1), __builtin_amdgcn_alignbyte(hi, lo, 2), __builtin_amdgcn_alignbyte(hi, lo, 3)};
         }
     };
     stage(s_a, Aimg, jo0, ALW);
@@ -203,8 +202,8 @@ __global__ void __launch_bounds__(NT) k_sad2(const uint8_t *__restrict__ Lp, con
             continue;
         }
         const int dmax = (view == 0) ? jo : (W - 1 - jo);                 // last in-range disparity
-        // dword index, inside a row's block of four copies, of the window's first full group and of its tail group
-        // (columns side - 4 .. side - 1): a full group g is then just "+ g", so the tap loop has no address arithmetic
+        // dword index, inside a row's expanded block, of the window's first full group and of its tail group
+        // (columns side - 4 .. side - 1): a full group g is then just "+ 4 g", so the tap loop has no address arithmetic
         int bfull[K], btail[K];
         unsigned acc[K];
 #pragma unroll
@@ -212,17 +211,17 @@ __global__ void __launch_bounds__(NT) k_sad2(const uint8_t *__restrict__ Lp, con
             const int d = lane + 64 * k;
             const int dd = d < dmax ? d : dmax;
             const int xs = ((view == 0) ? jo - dd : jo + dd) - xbase, xt = xs + side - 4;
-            bfull[k] = (xs & 3) * OLW + (xs >> 2);
-            btail[k] = (xt & 3) * OLW + (xt >> 2);
+            bfull[k] = xs;
+            btail[k] = xt;
             acc[k] = 0;
         }
-        const int afull = (p & 3) * ALW + (p >> 2), at = p + side - 4, atail = (at & 3) * ALW + (at >> 2);
+        const int afull = p, atail = p + side - 4;
         for (int r = 0; r < side; r++) {
             const unsigned *ra = s_a + (size_t)r * 4 * ALW, *ro = s_o + (size_t)r * 4 * OLW;
             for (int g = 0; g < nfull; g++) {
-                const unsigned a4 = ra[afull + g];
+                const unsigned a4 = ra[afull + 4 * g];
 #pragma unroll
-                for (int k = 0; k < K; k++) acc[k] = __builtin_amdgcn_sad_u8(a4, ro[bfull[k] + g], acc[k]);
+                for (int k = 0; k < K; k++) acc[k] = __builtin_amdgcn_sad_u8(a4, ro[bfull[k] + 4 * g], acc[k]);
             }
             if (rem) {
                 // the last dword ends at the row's last byte; the bytes already counted are masked out of both operands
@@ -1031,7 +1030,7 @@ SMT_API int smt_sad(const uint8_t *Lp, const uint8_t *Rp, int H, int W, int D, i
         return SMT_ERR_ARG;
     const int N = H * W;
     const int w = winsize + 1, side = 2 * w + 1, K = (D + 63) / 64, v = view == SMT_VIEW_LEFT ? 0 : 1;
-    // copy-row lengths in dwords, rounded up to 8 (mod 32): anchor bytes jo0 .. jo0 + STP + side - 2, other image
+    // dword columns staged per row (rounded up to 8 mod 32, a leftover of the separate-copies layout): anchor bytes jo0 .. jo0 + STP + side - 2, other image
     // 64 K - 1 more
     auto copy_words = [](int bytes) { int n = (bytes + 3) / 4 + 1; return n + ((8 - n % 32) % 32 + 32) % 32; };
     const int ALW = copy_words(STP + side - 1), OLW = copy_words(STP + side - 1 + 64 * K - 1);
