@@ -187,10 +187,12 @@ __global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, 
     const long p0 = (long)y0 * W + x0;
     // lane q: tap interval of pixel q relative to the first pixel; empty past the tile
     int lo = 1, hi = 0;
+    float myn = 1.0f;                                       // FINAL: lane q fetches pixel q's support count here, long before it is used
     if (lane < npx) {
         const uchar4 a = reinterpret_cast<const uchar4 *>(arms)[p0 + lane * stride];
         lo = lane - (HORIZ ? (int)a.x : (int)a.z);
         hi = lane + (HORIZ ? (int)a.y : (int)a.w);
+        if (FINAL) myn = (float)cnt[p0 + lane * stride];
     }
     int umin = 0, umax = npx - 1;                           // every pixel holds its own position
 #pragma unroll
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(NT) k_ca_pass2(const float *__restrict__ src, 
             // cost / count (cross_aggregator.cpp:389, float over uint16): the correctly rounded quotient without the division sequence
             // (wave_quotient, smt_common.h; k_ca_pass keeps the IEEE division as the independent formulation)
             float qv[C];
-            wave_quotient<C, FULL>(a, (float)cnt[p], dl, D, qv);
+            wave_quotient<C, FULL>(a, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myn), q)), dl, D, qv);
 #pragma unroll
             for (int k = 0; k < C; k++)
                 if (FULL || dl + k < D) o[k] = qv[k];
