@@ -23,11 +23,13 @@
 
 namespace {
 
-constexpr int NT = 256;
 #ifndef SMT_SCAN_PF
 #define SMT_SCAN_PF 8
 #endif
-constexpr int PF = SMT_SCAN_PF;            // prefetch depth (scan steps): loads are issued PF steps ahead so the
+#ifndef SMT_SCAN_PF_H
+#define SMT_SCAN_PF_H SMT_SCAN_PF
+#endif
+constexpr int PF_V = SMT_SCAN_PF, PF_H = SMT_SCAN_PF_H;   // prefetch depth (scan steps) of the vertical / horizontal passes: loads are issued PF steps ahead so the
                                   // in-order vmcnt wait never lands behind the step's own stores
 constexpr float PAD = 65535.0f;   // 0xffff as float (:151, :162, :169)
 
@@ -122,6 +124,7 @@ __device__ __forceinline__ void st_row(float *p, int dl, int D, const float (&sr
 template <int C, int PASS, int MODE, bool FULL>
 __device__ __forceinline__ void scan_body(const ScanArgs &a, float *out, int line)
 {
+    constexpr int PF = (PASS < 2) ? PF_H : PF_V;
     constexpr bool ACC = (MODE >= 1);
     constexpr bool ACC2 = (MODE == 3);
     constexpr bool WTA = (MODE == 2);
@@ -246,19 +249,32 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a, float *out, int lin
 #undef SMT_SCAN_STEP
 }
 
+// Threads per workgroup.  Every scanline of a pass is resident at once, so the pass ends with the CU that got the most
+// waves.  Rows (horizontal passes) have nothing in common: one wave per workgroup spreads H or 2 H of them evenly
+// (1080p: 270 or 540 workgroups of four waves leave some CUs with 8 or 12 waves and the rest with 4 or 8 -- the
+// left / right launch took 1.38 ms that way and takes 1.05 ms now).  Columns (vertical passes) are neighbours in memory:
+// four adjacent columns per workgroup read 3 KB runs, which measures 2 % better than one column per workgroup.
+#ifndef SMT_SCAN_NTLR
+#define SMT_SCAN_NTLR 64
+#endif
+#ifndef SMT_SCAN_NTS
+#define SMT_SCAN_NTS 256
+#endif
+constexpr int NTLR = SMT_SCAN_NTLR, NTS = SMT_SCAN_NTS;
+template <int PASS> constexpr int scan_nt() { return PASS < 2 ? NTLR : NTS; }
 template <int C, int PASS, int MODE, bool FULL>
-__global__ void __launch_bounds__(NT) k_scan(ScanArgs a)
+__global__ void __launch_bounds__(scan_nt<PASS>()) k_scan(ScanArgs a)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    scan_body<C, PASS, MODE, FULL>(a, a.out, blockIdx.x * (NT / 64) + wv);
+    scan_body<C, PASS, MODE, FULL>(a, a.out, blockIdx.x * (scan_nt<PASS>() / 64) + wv);
 }
 
 // left->right into a.out and right->left into a.out_b, concurrently (blockIdx.y picks the pass)
 template <int C, bool FULL>
-__global__ void __launch_bounds__(NT) k_scan_lr(ScanArgs a)
+__global__ void __launch_bounds__(NTLR) k_scan_lr(ScanArgs a)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int line = blockIdx.x * (NT / 64) + wv;
+    const int line = blockIdx.x * (NTLR / 64) + wv;
     if (blockIdx.y == 0) scan_body<C, 0, 0, FULL>(a, a.out, line);
     else scan_body<C, 1, 0, FULL>(a, a.out_b, line);
 }
@@ -309,12 +325,13 @@ template <int C, int MODE, bool FULL>
 static void launch_scan2(smt_scanline *h, int pass, const ScanArgs &a)
 {
     const int nlines = pass < 2 ? h->H : h->W;
-    dim3 grid((nlines + 3) / 4);
+    const int nt = pass < 2 ? NTLR : NTS;
+    dim3 grid((nlines + nt / 64 - 1) / (nt / 64));
     switch (pass) {
-    case 0: hipLaunchKernelGGL((k_scan<C, 0, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((k_scan<C, 1, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_scan<C, 2, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
-    default: hipLaunchKernelGGL((k_scan<C, 3, MODE, FULL>), grid, dim3(NT), 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((k_scan<C, 0, MODE, FULL>), grid, dim3(nt), 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_scan<C, 1, MODE, FULL>), grid, dim3(nt), 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_scan<C, 2, MODE, FULL>), grid, dim3(nt), 0, h->stream, a); break;
+    default: hipLaunchKernelGGL((k_scan<C, 3, MODE, FULL>), grid, dim3(nt), 0, h->stream, a); break;
     }
 }
 
@@ -339,9 +356,9 @@ static void launch_scan(smt_scanline *h, int pass, const ScanArgs &a, int mode)
 template <int C>
 static void launch_lr(smt_scanline *h, const ScanArgs &a)
 {
-    dim3 grid((h->H + 3) / 4, 2);
-    if (C <= 4 && h->D == 64 * C) hipLaunchKernelGGL((k_scan_lr<(C <= 4 ? C : 1), true>), grid, dim3(NT), 0, h->stream, a);
-    else hipLaunchKernelGGL((k_scan_lr<C, false>), grid, dim3(NT), 0, h->stream, a);
+    dim3 grid((h->H + NTLR / 64 - 1) / (NTLR / 64), 2);
+    if (C <= 4 && h->D == 64 * C) hipLaunchKernelGGL((k_scan_lr<(C <= 4 ? C : 1), true>), grid, dim3(NTLR), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_scan_lr<C, false>), grid, dim3(NTLR), 0, h->stream, a);
 }
 
 static int scan_pass(smt_scanline *h, const ScanArgs &a, int pass, int mode)
