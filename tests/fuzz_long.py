@@ -1,9 +1,10 @@
 """Long randomized parity run (not collected by pytest): AD-Census both views + WTA (D up to 512), every union-sharing
-aggregation kernel (variants 3-13, the matrix-pipe forms included), SAD (both formulations) and ASW (all formulations)
-against the oracle at random shapes for ~150 s.
+aggregation kernel (variants 3-13, the matrix-pipe forms included), SAD (both formulations), ASW (all formulations), NCC (both
+formulations), the scanline optimiser and CrossAggregator against the oracle at random shapes for ~150 s.
 usage on the GPU box: python tests/fuzz_long.py [seed] [seconds]
 (last runs, round 3: seed 4242, 240 s: 2 538 cases of each of the four families; seed 777, 300 s with the batch entry under
-random schedules and aggregation variant 13: 1 202 cases of each; all bit-exact)"""
+random schedules and aggregation variant 13: 1 202 cases of each; seed 2024, 400 s on the round's final code with NCC, the
+scanline optimiser and CrossAggregator added: 1 634 cases of each family; all bit-exact)"""
 import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +19,10 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 12345
 rng = np.random.default_rng(seed)
 t0 = time.time(); n_adc = n_agg = 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
-n_sad = n_asw = 0
+n_sad = n_asw = n_more = 0
+t_say = t0
 while time.time() - t0 < budget:
+    if time.time() - t_say > 60: t_say = time.time(); print("...", int(t_say - t0), "s", n_adc, "cases", flush=True)
     # ---- AD-Census: both views + WTA at random shapes
     H, W = int(rng.integers(1, 40)), int(rng.integers(1, 300))
     D = int(rng.choice([1, 2, 7, 16, 63, 64, 65, 100, 128, 129, 191, 192, 193, 255, 256, 257, 320, 400, 512]))
@@ -98,4 +101,49 @@ while time.time() - t0 < budget:
         assert np.array_equal(np.isnan(c), np.isnan(ref_c)) and np.array_equal(bits(c[ok]), bits(ref_c[ok])), ("asw", H, W, D, ws, view, impl)
         assert np.array_equal(dd.cpu().numpy(), rd), ("aswmap", H, W, D, ws, view, impl)
     smt.asw_set_impl(0); n_asw += 1
-print("fuzz ok: seed", seed, "adcensus cases", n_adc, "aggregation cases", n_agg, "sad cases", n_sad, "asw cases", n_asw)
+    # ---- NCC: both formulations against each other (costs to 1e-12, same NaN pattern) and the oracle's map
+    H, W = int(rng.integers(3, 26)), int(rng.integers(3, 120))
+    D = int(rng.choice([1, 5, 33, 61, 64, 65, 100, 125, 126, 128, 189, 190, 200, 253, 254, 256])); win = int(rng.integers(0, 6))
+    Ln = rng.integers(0, 256, (H, W)).astype(np.uint8) if rng.integers(0, 2) else O.synth_pair(H, W, 16, int(rng.integers(0, 1000)))[0].copy()
+    Rn = (Ln.astype(np.int32) + rng.integers(-2, 3, (H, W))).clip(0, 255).astype(np.uint8) if rng.integers(0, 2) else rng.integers(0, 256, (H, W)).astype(np.uint8)
+    if H > 6 and W > 10: Ln[1:H // 2, 2:W // 2] = 77; Rn[0:H // 2 + 1, 0:W // 2 + 3] = 77        # flat patches: 0/0
+    rd = O.ncc(Ln, Rn, D, win)
+    got = []
+    for impl in (2, 1):
+        smt.ncc_set_impl(impl)
+        dn, cn = smt.NCC_algorithem(T(Ln), T(Rn), win, D, want_cost=True)
+        assert np.array_equal(dn.cpu().numpy(), rd), ("ncc map", H, W, D, win, impl)
+        got.append(cn.cpu().numpy())
+    smt.ncc_set_impl(2)
+    if H > 2 * win and W > 2 * win:
+        a, b = got[0][win:H - win, win:W - win], got[1][win:H - win, win:W - win]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), ("ncc nan", H, W, D, win)
+        ok = ~np.isnan(a)
+        assert not ok.any() or np.max(np.abs(a[ok] - b[ok])) <= 1e-12, ("ncc cost", H, W, D, win)
+    # ---- scanline optimiser (4 passes + WTA) and CrossAggregator
+    H, W = int(rng.integers(1, 14)), int(rng.integers(1, 60))
+    D = int(rng.choice([1, 3, 16, 63, 64, 65, 128, 130, 192, 256, 300]))
+    cost = rng.random((H, W, D), dtype=np.float32) * 3
+    gray = rng.integers(0, 256, (H, W)).astype(np.float32)
+    p1, p2 = int(rng.choice([10, 1, 0])), int(rng.choice([150, 3, 40]))
+    so = smt.ScanlineOptimizer().Initialize(H, W, D, p1, p2, DEV)
+    dsp = torch.empty((H, W), device=DEV)
+    out = so.ScanLine(T(cost), T(gray), disp=dsp)
+    ref = O.scanline(cost, gray, p1, p2)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref)), ("scan", H, W, D, p1, p2)
+    assert np.array_equal(dsp.cpu().numpy(), O.wta(ref)), ("scan wta", H, W, D)
+    so.close()
+    H, W = int(rng.integers(2, 30)), int(rng.integers(2, 50))
+    D = int(rng.choice([1, 8, 64, 70, 192]))
+    g8 = rng.integers(0, 256, (H, W)).astype(np.uint8) if rng.integers(0, 2) else O.synth_pair(H, W, 16, int(rng.integers(0, 1000)))[0]
+    bgr = np.clip(g8[..., None].astype(np.int32) + rng.integers(0, 3, (H, W, 3)), 0, 255).astype(np.uint8)
+    cst = (rng.random((H, W, D), dtype=np.float32) * np.exp2(rng.integers(-70, 70, D)).astype(np.float32)) if rng.integers(0, 2) else rng.random((H, W, D), dtype=np.float32)
+    L1, L2, t1, t2, iters = int(rng.choice([34, 5, 60])), int(rng.choice([17, 2])), int(rng.choice([20, 8])), int(rng.choice([6, 3])), int(rng.integers(0, 5))
+    a_ref, c_ref = O.crossagg(bgr, cst, L1, L2, t1, t2, iters)
+    agg = smt.CrossAggregator(); assert agg.Initialize(W, H, 0, D, DEV)
+    agg.SetData(T(bgr), T(bgr), T(cst)); agg.SetParams(L1, L2, t1, t2); agg.Aggregate(iters)
+    assert np.array_equal(agg.get_arms_ptr().cpu().numpy(), a_ref), ("ca arms", H, W)
+    assert np.array_equal(bits(agg.get_cost_ptr().cpu().numpy()), bits(c_ref)), ("ca cost", H, W, D, iters)
+    agg.close(); n_more += 1
+print("fuzz ok: seed", seed, "adcensus cases", n_adc, "aggregation cases", n_agg, "sad cases", n_sad, "asw cases", n_asw,
+      "ncc + scanline + crossaggregator cases", n_more)
