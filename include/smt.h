@@ -181,6 +181,11 @@ int smt_adcensus_volume(smt_adcensus *h, int view, float **vol);
  * independent formulation kept for cross-checking) instead of the register-window kernel. */
 int smt_adcensus_force_generic(smt_adcensus *h, int on);
 
+/* Test hook, host only (no GPU): checks the workgroup arithmetic of the fused batch launch -- with `ncost` cost
+ * workgroups (a multiple of 8) and `nprep` table workgroups every cost group and every table group is reached exactly
+ * once.  SMT_OK, or SMT_ERR_STATE if the mapping is not a bijection. */
+int smt_adcensus_selftest_fused_grid(int ncost, int nprep);
+
 /* Synchronises the stream and returns SMT_ERR_DOMAIN if any pixel seen since the previous
  * smt_adcensus_status call (or since create) was not an integer in 0..255 (then those pairs' volumes
  * are unspecified), else SMT_OK.  Read-and-clear: a bad pair does not poison later checks.  Bad input is

@@ -634,7 +634,7 @@ __host__ __device__ inline FusedGrid fused_grid(int ncost, int nprep)
     return f;
 }
 // group g of the fused grid -> (true, table group) or (false, cost group)
-__device__ __forceinline__ bool fused_decode(const FusedGrid &f, int g, int &idx)
+__host__ __device__ inline bool fused_decode(const FusedGrid &f, int g, int &idx)
 {
     const int period = f.every + 1, inter = f.slots * period;
     if (g < inter) {
@@ -1258,6 +1258,33 @@ SMT_API int smt_adcensus_status(smt_adcensus *h)
     SMT_HIP(hipMemsetAsync(h->T.flag, 0, 4, h->stream));            // read-and-clear
     SMT_HIP(hipStreamSynchronize(h->stream));
     return f ? SMT_ERR_DOMAIN : SMT_OK;
+}
+
+// Host-side check of the fused launch's workgroup arithmetic (fused_grid / fused_decode, the functions the kernel runs):
+// every cost group and every table group of a launch with `ncost` cost and `nprep` table workgroups is reached exactly
+// once.  Needs no GPU.
+SMT_API int smt_adcensus_selftest_fused_grid(int ncost, int nprep)
+{
+    if (ncost <= 0 || (ncost & 7) || nprep <= 0) return SMT_ERR_ARG;
+    const FusedGrid f = fused_grid(ncost, nprep);
+    if (f.groups < f.cgroups + f.pgroups) return SMT_ERR_STATE;
+    unsigned char *seen = new (std::nothrow) unsigned char[(size_t)2 * f.groups]();
+    if (!seen) return SMT_ERR_ALLOC;
+    int rc = SMT_OK, ntab = 0;
+    for (int g = 0; g < f.groups && rc == SMT_OK; g++) {
+        int idx = -1;
+        const bool table = fused_decode(f, g, idx);
+        if (idx < 0 || idx >= f.groups || (!table && idx >= f.cgroups)) { rc = SMT_ERR_STATE; break; }
+        unsigned char &cell = seen[(table ? f.groups : 0) + idx];
+        if (cell) rc = SMT_ERR_STATE;
+        cell = 1;
+        ntab += table;
+    }
+    for (int c = 0; c < f.cgroups && rc == SMT_OK; c++) if (!seen[c]) rc = SMT_ERR_STATE;              // every cost group
+    for (int t = 0; t < ntab && rc == SMT_OK; t++) if (!seen[f.groups + t]) rc = SMT_ERR_STATE;         // table groups 0 .. ntab - 1
+    if (rc == SMT_OK && ntab < f.pgroups) rc = SMT_ERR_STATE;
+    delete[] seen;
+    return rc;
 }
 
 SMT_API int smt_adcensus_force_generic(smt_adcensus *h, int on)

@@ -73,6 +73,27 @@ def test_lib_exports_every_declared_symbol():
     assert lib.smt_version() == 100
 
 
+def test_fused_launch_grid_is_a_bijection():
+    """smt_adcensus_compute_batch puts the table workgroups of pair n+1 into the grid of pair n's cost launch in groups
+    of 8 (adcensus.hip: fused_grid / fused_decode).  The library's own host-side check of that arithmetic, over the
+    benchmark shapes, tiny grids and random sizes: every cost group and every table group exactly once."""
+    from stereo_match_traditional_amd import build
+    lib = ctypes.CDLL(build.build())
+    f = lib.smt_adcensus_selftest_fused_grid
+    shapes = [(1080, 1920), (720, 1280), (375, 1242), (1, 1), (2, 70), (33, 64), (700, 3)]
+    for H, W in shapes:
+        nbx = (W + 63) // 64
+        ncost = (nbx * H * 2 + 7) // 8 * 8
+        ptx, pty, eb = (W + 63) // 64, (H + 31) // 32, (H + 15) // 16
+        nprep = ptx * (pty + (eb + ptx - 1) // ptx)
+        assert f(ncost, nprep) == 0, (H, W, ncost, nprep)
+    rng = np.random.default_rng(3)
+    for _ in range(3000):
+        ncost, nprep = 8 * int(rng.integers(1, 4000)), int(rng.integers(1, 6000))
+        assert f(ncost, nprep) == 0, (ncost, nprep)
+    assert f(12, 5) != 0 and f(0, 5) != 0 and f(8, 0) != 0          # rejected arguments
+
+
 def test_oracle_vs_golden_fixtures(O):
     """Oracle vs the committed fixtures (CrossAggregator outputs of the reference build;
     expf tables of the build container's libm)."""
